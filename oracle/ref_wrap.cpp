@@ -1,0 +1,196 @@
+// TEST INFRASTRUCTURE — not product code.
+//
+// Harness around the reference headers compiled verbatim (oracle/build_ref.sh puts a mechanically
+// qualifier-rewritten copy of /root/reference/ffx-fsr/{ffx_a.h,ffx_fsr1.h} in a temp include dir
+// as ref_ffx_a.h / ref_ffx_fsr1.h; nothing of the reference is stored in this repository).
+// The harness plays the role of the dispatch shell sample/src/DX12/FSR_Pass.hlsl:39-62 (callbacks)
+// and :68-104 (CurrFilter): gather4 with clamp-to-edge for EASU, integer Load with zero outside
+// the image for RCAS, alpha written as 1.
+//
+// Exposed as a C ABI over plain float buffers (RGBA interleaved, 4 floats per pixel) so the tests
+// and bench.py's cpu_baseline leg can call it through ctypes.  "H" entry points take/return floats
+// whose values are binary16-representable.
+#include "ref_glsl_shim.hpp"
+
+#include <cstdint>
+#include <cstdlib>
+#include <omp.h>
+
+namespace glsl {
+
+struct Image {
+  const float* p;
+  int w, h;
+};
+static thread_local Image g_src;
+
+// gather4 at normalized coordinate p for channel c: returns texels
+//   x=(i,j+1) y=(i+1,j+1) z=(i+1,j) w=(i,j),  i=floor(p.x*W-0.5), j=floor(p.y*H-0.5), clamp-to-edge
+// (D3D/Vulkan gather semantics; sampler is CLAMP: sample/src/DX12/FSR_Filter.cpp:48-53).
+static inline float texel(int x, int y, int c) {
+  x = x < 0 ? 0 : (x >= g_src.w ? g_src.w - 1 : x);
+  y = y < 0 ? 0 : (y >= g_src.h ? g_src.h - 1 : y);
+  return g_src.p[((size_t)y * g_src.w + x) * 4 + c];
+}
+static inline vec4 gather(vec2 p, int c) {
+  int i = (int)std::floor(p.x * (float)g_src.w - 0.5f);
+  int j = (int)std::floor(p.y * (float)g_src.h - 0.5f);
+  return vec4(texel(i, j + 1, c), texel(i + 1, j + 1, c), texel(i + 1, j, c), texel(i, j, c));
+}
+// integer load; outside the resource returns 0 (D3D Load semantics, FSR_Pass.hlsl:45,61)
+static inline vec4 load(int x, int y) {
+  if (x < 0 || y < 0 || x >= g_src.w || y >= g_src.h) return vec4(0.f, 0.f, 0.f, 0.f);
+  const float* q = g_src.p + ((size_t)y * g_src.w + x) * 4;
+  return vec4(q[0], q[1], q[2], q[3]);
+}
+
+#define A_GPU 1
+#define A_GLSL 1
+#define A_SKIP_EXT 1
+#define A_HALF 1
+#define FSR_EASU_F 1
+#define FSR_EASU_H 1
+#define FSR_RCAS_F 1
+#define FSR_RCAS_H 1
+
+#define REF_CALLBACKS                                                                                   \
+  vec4 FsrEasuRF(vec2 p) { return gather(p, 0); }                                                       \
+  vec4 FsrEasuGF(vec2 p) { return gather(p, 1); }                                                       \
+  vec4 FsrEasuBF(vec2 p) { return gather(p, 2); }                                                       \
+  f16vec4 FsrEasuRH(vec2 p) { return f16vec4(gather(p, 0)); }                                           \
+  f16vec4 FsrEasuGH(vec2 p) { return f16vec4(gather(p, 1)); }                                           \
+  f16vec4 FsrEasuBH(vec2 p) { return f16vec4(gather(p, 2)); }                                           \
+  vec4 FsrRcasLoadF(ivec2 p) { return load(p.x, p.y); }                                                 \
+  void FsrRcasInputF(float& r, float& g, float& b) {}                                                   \
+  f16vec4 FsrRcasLoadH(i16vec2 p) { return f16vec4(load(p.x, p.y)); }                                   \
+  void FsrRcasInputH(float16_t& r, float16_t& g, float16_t& b) {}
+
+// Four builds of the same header: the RCAS feature macros are compile-time (ffx_fsr1.h:647-651).
+namespace plain {
+REF_CALLBACKS
+#include "ref_ffx_a.h"
+#include "ref_ffx_fsr1.h"
+}  // namespace plain
+namespace denoise {
+#define FSR_RCAS_DENOISE 1
+REF_CALLBACKS
+#include "ref_ffx_a.h"
+#include "ref_ffx_fsr1.h"
+#undef FSR_RCAS_DENOISE
+}  // namespace denoise
+namespace alpha {
+#define FSR_RCAS_PASSTHROUGH_ALPHA 1
+REF_CALLBACKS
+#include "ref_ffx_a.h"
+#include "ref_ffx_fsr1.h"
+}  // namespace alpha
+namespace alpha_denoise {
+#define FSR_RCAS_DENOISE 1
+REF_CALLBACKS
+#include "ref_ffx_a.h"
+#include "ref_ffx_fsr1.h"
+#undef FSR_RCAS_DENOISE
+#undef FSR_RCAS_PASSTHROUGH_ALPHA
+}  // namespace alpha_denoise
+
+static inline uvec4 con4(const uint32_t* c) { return uvec4(c[0], c[1], c[2], c[3]); }
+
+}  // namespace glsl
+
+using namespace glsl;
+
+enum { REF_RCAS_DENOISE = 1, REF_RCAS_ALPHA = 2, REF_HDR_SQUARE = 4 };
+
+extern "C" {
+
+// Rows [y0,y1) of the EASU output.  con16 = con0..con3 as produced by FsrEasuCon.
+// flags & REF_HDR_SQUARE reproduces `if (Sample.x == 1) c *= c;` (FSR_Pass.hlsl:78-79).
+void ref_easu_f(const float* in, int inW, int inH, float* out, int outW, int outH, const uint32_t* con16,
+                int flags, int y0, int y1) {
+#pragma omp parallel for schedule(dynamic, 4)
+  for (int y = y0; y < y1; ++y) {
+    g_src = Image{in, inW, inH};
+    for (int x = 0; x < outW; ++x) {
+      vec3 c;
+      plain::FsrEasuF(c, uvec2((uint)x, (uint)y), con4(con16), con4(con16 + 4), con4(con16 + 8), con4(con16 + 12));
+      if (flags & REF_HDR_SQUARE) c *= c;
+      float* o = out + ((size_t)y * outW + x) * 4;
+      o[0] = c.x; o[1] = c.y; o[2] = c.z; o[3] = 1.0f;
+    }
+  }
+}
+
+void ref_easu_h(const float* in, int inW, int inH, float* out, int outW, int outH, const uint32_t* con16,
+                int flags, int y0, int y1) {
+#pragma omp parallel for schedule(dynamic, 4)
+  for (int y = y0; y < y1; ++y) {
+    g_src = Image{in, inW, inH};
+    for (int x = 0; x < outW; ++x) {
+      f16vec3 c;
+      plain::FsrEasuH(c, uvec2((uint)x, (uint)y), con4(con16), con4(con16 + 4), con4(con16 + 8), con4(con16 + 12));
+      if (flags & REF_HDR_SQUARE) c *= c;
+      float* o = out + ((size_t)y * outW + x) * 4;
+      o[0] = c.x.v; o[1] = c.y.v; o[2] = c.z.v; o[3] = 1.0f;
+    }
+  }
+}
+
+// Rows [y0,y1) of RCAS on a W x H image.  flags: REF_RCAS_DENOISE, REF_RCAS_ALPHA, REF_HDR_SQUARE.
+void ref_rcas_f(const float* in, int W, int H, float* out, const uint32_t* con, int flags, int y0, int y1) {
+#pragma omp parallel for schedule(dynamic, 4)
+  for (int y = y0; y < y1; ++y) {
+    g_src = Image{in, W, H};
+    for (int x = 0; x < W; ++x) {
+      vec3 c;
+      float a = 1.0f;
+      uvec2 ip((uint)x, (uint)y);
+      switch (flags & 3) {
+        case 0: plain::FsrRcasF(c.r, c.g, c.b, ip, con4(con)); break;
+        case REF_RCAS_DENOISE: denoise::FsrRcasF(c.r, c.g, c.b, ip, con4(con)); break;
+        case REF_RCAS_ALPHA: alpha::FsrRcasF(c.r, c.g, c.b, a, ip, con4(con)); break;
+        default: alpha_denoise::FsrRcasF(c.r, c.g, c.b, a, ip, con4(con)); break;
+      }
+      if (flags & REF_HDR_SQUARE) c *= c;
+      float* o = out + ((size_t)y * W + x) * 4;
+      o[0] = c.x; o[1] = c.y; o[2] = c.z; o[3] = a;
+    }
+  }
+}
+
+void ref_rcas_h(const float* in, int W, int H, float* out, const uint32_t* con, int flags, int y0, int y1) {
+#pragma omp parallel for schedule(dynamic, 4)
+  for (int y = y0; y < y1; ++y) {
+    g_src = Image{in, W, H};
+    for (int x = 0; x < W; ++x) {
+      f16vec3 c;
+      float16_t a(1.0);
+      uvec2 ip((uint)x, (uint)y);
+      switch (flags & 3) {
+        case 0: plain::FsrRcasH(c.r, c.g, c.b, ip, con4(con)); break;
+        case REF_RCAS_DENOISE: denoise::FsrRcasH(c.r, c.g, c.b, ip, con4(con)); break;
+        case REF_RCAS_ALPHA: alpha::FsrRcasH(c.r, c.g, c.b, a, ip, con4(con)); break;
+        default: alpha_denoise::FsrRcasH(c.r, c.g, c.b, a, ip, con4(con)); break;
+      }
+      if (flags & REF_HDR_SQUARE) c *= c;
+      float* o = out + ((size_t)y * W + x) * 4;
+      o[0] = c.x.v; o[1] = c.y.v; o[2] = c.z.v; o[3] = a.v;
+    }
+  }
+}
+
+// The A_GPU build of the constant setup (same source lines as the A_CPU build, ffx_fsr1.h:156-225,
+// 662-672) — exported so the tests can confirm both builds of the reference agree.
+void ref_easu_con_gpu(uint32_t* con16, float vpW, float vpH, float inW, float inH, float outW, float outH) {
+  uvec4 c0, c1, c2, c3;
+  plain::FsrEasuCon(c0, c1, c2, c3, vpW, vpH, inW, inH, outW, outH);
+  for (int i = 0; i < 4; ++i) { con16[i] = c0[i]; con16[4 + i] = c1[i]; con16[8 + i] = c2[i]; con16[12 + i] = c3[i]; }
+}
+
+// ARmp8x8 lane -> (x,y) remap used by the dispatch shell (ffx_a.h:2304, FSR_Pass.hlsl:110).
+void ref_rmp8x8(uint32_t lane, uint32_t* xy) {
+  uvec2 r = plain::ARmp8x8(lane);
+  xy[0] = r.x; xy[1] = r.y;
+}
+
+int ref_omp_threads(void) { return omp_get_max_threads(); }
+}
