@@ -1,0 +1,219 @@
+#!/usr/bin/env python3
+"""Headline benchmark: upscaled megapixels/s of the FSR 1.0 hot path (EASU + RCAS) on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
+
+A "step" is one pass of the hot path over one batch of synthetic frames that are already resident
+in HBM.  Default workload = BASELINE.json configs[1]: 1920x1080 -> 3840x2160, EASU + RCAS, RGBA16F
+storage, one frame per step and per GPU, default ("F") arithmetic = fp32 math within 1 binary16 ULP of
+the reference's CPU-evaluated FsrEasuF/FsrRcasF.  Steps rotate over a ring of distinct frame sets
+larger than the 256 MiB Infinity Cache, so every step streams from HBM like a video pipeline would.
+Frames are independent, so N GPUs run N independent streams (weak scaling); the only collective is
+the reduction of the throughput counters.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "oracle")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured copy ceiling
+
+WORKLOADS = {
+    # name: (in_w, in_h, out_w, out_h, frames per step per GPU)
+    "1080p_to_4k": (1920, 1080, 3840, 2160, 1),          # BASELINE configs[1] (and [3] when --pipeline fused)
+    "540p_to_1080p": (960, 540, 1920, 1080, 1),          # configs[0] shape
+    "1440p_to_4k_x8": (2560, 1440, 3840, 2160, 8),       # configs[2]: 64 frames over 8 GPUs
+    "4k_to_8k_x16": (3840, 2160, 7680, 4320, 16),        # configs[4]: 128 frames over 8 GPUs
+}
+
+
+def reduce_counters(frames, pixels, seconds, device):
+    """Whole-job counters: SUM of frames/pixels, MAX of seconds over ranks (identity without a process group).
+    This is the only collective of the multi-GPU path (RCCL over xGMI on GPUs, gloo in the CPU tests)."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return {"frames": int(frames), "pixels": int(pixels), "seconds": float(seconds)}
+    s = torch.tensor([float(frames), float(pixels)], dtype=torch.float64, device=device)
+    m = torch.tensor([float(seconds)], dtype=torch.float64, device=device)
+    dist.all_reduce(s, op=dist.ReduceOp.SUM)
+    dist.all_reduce(m, op=dist.ReduceOp.MAX)
+    return {"frames": int(round(s[0].item())), "pixels": int(round(s[1].item())), "seconds": float(m[0].item())}
+
+
+def cpu_baseline(fsr, in_w, in_h, out_w, out_h, target_seconds=12.0):
+    """The reference path on the host cores: oracle/_ref (the reference headers compiled verbatim; kind
+    "reference") when it travelled with the tree, else the plain-C restatement (kind "port"); OpenMP over
+    output rows on all host cores; a bounded band of rows of the same workload (EASU-F then RCAS-F)."""
+    import numpy as np
+    import cpu_oracle
+    o = cpu_oracle.ref() if cpu_oracle.have_ref() else cpu_oracle.port()
+    img = fsr.frames.synthetic_frame(in_w, in_h, k=0, dtype=np.float32)
+    con = o.FsrEasuCon(in_w, in_h, in_w, in_h, out_w, out_h)
+    rc = o.FsrRcasCon(0.25)
+    rows = min(out_h, 64)
+    t0 = time.perf_counter()
+    o.easu_f(img, out_w, out_h, con, 0, (0, rows))
+    probe = time.perf_counter() - t0
+    rows = int(max(rows, min(out_h, rows * (target_seconds * 0.8) / max(probe, 1e-3))))
+    t0 = time.perf_counter()
+    mid = o.easu_f(img, out_w, out_h, con, 0, (0, rows))
+    t_easu = time.perf_counter() - t0
+    mid = mid.astype(np.float16).astype(np.float32)
+    t0 = time.perf_counter()
+    o.rcas_f(mid, rc, 0, (0, rows))
+    t_rcas = time.perf_counter() - t0
+    mpix = rows * out_w / 1e6
+    return {
+        "value": round(mpix / (t_easu + t_rcas), 3), "unit": "Mpix/s", "cores": int(o.threads), "kind": o.kind,
+        "sample": "rows 0..%d of one %dx%d->%dx%d frame, FsrEasuF then FsrRcasF (fp32), OpenMP over rows; easu %.2f s + rcas %.2f s"
+                  % (rows, in_w, in_h, out_w, out_h, t_easu, t_rcas),
+        "easu_mpix_s": round(mpix / t_easu, 3), "rcas_mpix_s": round(mpix / t_rcas, 3),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="1080p_to_4k", choices=sorted(WORKLOADS))
+    ap.add_argument("--pipeline", default="two-pass", choices=["two-pass", "fused", "easu"])
+    ap.add_argument("--math", default="f", choices=["f", "exact", "h"], help="f: fp32 math (default); exact: reference op order; h: packed fp16")
+    ap.add_argument("--ring", type=int, default=0, help="distinct frame sets to rotate over (0 = enough to exceed 256 MiB)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    fsr = importlib.import_module("fidelityfx-fsr_amd")
+    fsr.load()  # raises if the HIP library is not built: no fallback
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+        raise SystemExit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the FSR1 HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)  # "nccl" is RCCL on ROCm
+
+    in_w, in_h, out_w, out_h, frames = WORKLOADS[args.workload]
+    math_flags = {"f": 0, "exact": fsr.FLAG_MATH_EXACT, "h": fsr.FLAG_MATH_PACKED_FP16}[args.math]
+    px = 8  # RGBA16F
+    in_bytes, out_bytes = in_w * in_h * px * frames, out_w * out_h * px * frames
+    set_bytes = in_bytes + out_bytes * (2 if args.pipeline == "two-pass" else 1)
+    ring = args.ring or max(2, -(-320 * 2**20 // set_bytes))
+
+    # synthetic frames: a few distinct numpy frames uploaded once, then varied on-device per ring slot
+    base = [torch.from_numpy(fsr.frames.synthetic_frame(in_w, in_h, k=k + 16 * rank)).to(device) for k in range(min(frames, 2))]
+    srcs, mids, dsts = [], [], []
+    for s in range(ring):
+        t = torch.stack([torch.roll(base[f % len(base)], shifts=(3 * s + f, 5 * s + 2 * f), dims=(0, 1)) for f in range(frames)])
+        srcs.append(t.contiguous())
+        mids.append(torch.empty(frames, out_h, out_w, 4, dtype=torch.float16, device=device) if args.pipeline == "two-pass" else None)
+        dsts.append(torch.empty(frames, out_h, out_w, 4, dtype=torch.float16, device=device))
+    easu_con = fsr.FsrEasuCon(in_w, in_h, in_w, in_h, out_w, out_h)
+    rcas_con = fsr.FsrRcasCon(0.25)  # sample default attenuation (SampleRenderer.h:49)
+
+    def step(i):
+        s = i % ring
+        if args.pipeline == "two-pass":
+            fsr.easu(srcs[s], mids[s], con=easu_con, flags=math_flags)
+            fsr.rcas(mids[s], dsts[s], con=rcas_con, flags=math_flags)
+        elif args.pipeline == "fused":
+            fsr.easu_rcas_fused(srcs[s], dsts[s], easu_con=easu_con, rcas_con=rcas_con, flags=math_flags)
+        else:
+            fsr.easu(srcs[s], dsts[s], con=easu_con, flags=math_flags)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    fence()
+    seconds = time.perf_counter() - t0
+
+    total = reduce_counters(frames * args.steps, frames * args.steps * out_w * out_h, seconds, device)
+    value = total["pixels"] / total["seconds"] / 1e6
+
+    # ---- per-kernel durations with HIP events on the launch stream (C-ABI stopwatch) ----
+    timer = fsr.Timer()
+
+    def kernel_ms(fn, n):
+        for i in range(3):
+            fn(i)
+        torch.cuda.synchronize()
+        timer.start()
+        for i in range(n):
+            fn(i)
+        timer.stop()
+        return timer.elapsed_ms() / n
+
+    n_k = max(20, min(args.steps, 200))
+    kern = {}
+    if args.pipeline in ("two-pass", "easu"):
+        tgt = mids if args.pipeline == "two-pass" else dsts
+        kern["easu"] = kernel_ms(lambda i: fsr.easu(srcs[i % ring], tgt[i % ring], con=easu_con, flags=math_flags), n_k)
+    if args.pipeline == "two-pass":
+        kern["rcas"] = kernel_ms(lambda i: fsr.rcas(mids[i % ring], dsts[i % ring], con=rcas_con, flags=math_flags), n_k)
+    if args.pipeline == "fused":
+        kern["fused"] = kernel_ms(lambda i: fsr.easu_rcas_fused(srcs[i % ring], dsts[i % ring], easu_con=easu_con, rcas_con=rcas_con, flags=math_flags), n_k)
+
+    # algorithmic HBM bytes per launch: EASU in+out, RCAS 2*out, fused in+out
+    alg = {"easu": in_bytes + out_bytes, "rcas": 2 * out_bytes, "fused": in_bytes + out_bytes}
+    dominant = max(kern, key=kern.get)
+
+    def roof(name):
+        gbps = alg[name] / (kern[name] * 1e-3) / 1e9
+        return {"kernel": name, "bound": "hbm", "achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": round(gbps / HBM_PEAK_GBPS, 4), "traffic": None, "algorithmic_bytes": alg[name],
+                "avg_kernel_us": round(kern[name] * 1e3, 2)}
+
+    if rank == 0:
+        line = {
+            "metric": "upscaled megapixels/sec (EASU+RCAS, 1080p->4K fp16)" if args.pipeline != "easu" else "upscaled megapixels/sec (EASU only)",
+            "value": round(value, 1), "unit": "Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(total["seconds"] * 1e3 / args.steps, 5), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32" if args.math != "h" else "f16", "data": "synthetic",
+            "config": {"workload": "%s: %dx%d -> %dx%d RGBA16F, %d frame(s)/step/GPU, %s, math=%s, ring of %d frame sets"
+                                   % (args.workload, in_w, in_h, out_w, out_h, frames, args.pipeline, args.math, ring),
+                       "pipeline": args.pipeline, "storage": "rgba16f", "rcas_sharpness_stops": 0.25,
+                       "parallelism": "independent frames per GPU, counters-only collective"},
+            "roofline": roof(dominant),
+            "kernels": {k: roof(k) for k in kern},
+            "pipeline_hbm": {"algorithmic_bytes_per_step": sum(alg[k] for k in kern),
+                             "achieved_GBps": round(sum(alg[k] for k in kern) * args.steps / seconds / 1e9, 1)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(fsr, in_w, in_h, out_w, out_h)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

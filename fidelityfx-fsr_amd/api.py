@@ -1,0 +1,233 @@
+"""Host-side mirror of the reference's operator surface for the EASU+RCAS hot path.
+
+Names, argument order and meaning follow the reference:
+  FsrEasuCon / FsrEasuConOffset / FsrRcasCon      ffx-fsr/ffx_fsr1.h:156-225, :662-672
+  FSR_Filter.{OnCreate, OnCreateWindowSizeDependentResources, Upscale, OnDestroy}
+                                                   sample/src/DX12/FSR_Filter.{h,cpp}
+Everything that touches pixels goes through the C ABI of libfsr1_hip.so; torch is used only to own
+device memory and to name the stream.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from ._lib import Fsr1Error, fsr1_image, fsr1_params  # noqa: F401
+
+FORMAT_RGBA16F = 0
+FORMAT_RGBA32F = 1
+
+FLAG_HDR_SQUARE = 1 << 0
+FLAG_RCAS_DENOISE = 1 << 1
+FLAG_RCAS_PASSTHROUGH_ALPHA = 1 << 2
+FLAG_MATH_EXACT = 1 << 4
+FLAG_MATH_PACKED_FP16 = 1 << 5
+
+_U32P = ctypes.POINTER(ctypes.c_uint32)
+
+
+def _u32p(a, off=0):
+    return ctypes.cast(a.ctypes.data + 4 * off, _U32P)
+
+
+# --------------------------------------------------------------------------------------------------
+# constant setup (host)
+# --------------------------------------------------------------------------------------------------
+def FsrEasuCon(inputViewportInPixelsX, inputViewportInPixelsY, inputSizeInPixelsX, inputSizeInPixelsY,
+               outputSizeInPixelsX, outputSizeInPixelsY):
+    """-> uint32[16] = con0 | con1 | con2 | con3 (ffx_fsr1.h:156-202)."""
+    c = np.zeros(16, np.uint32)
+    _lib.load().FsrEasuCon(_u32p(c, 0), _u32p(c, 4), _u32p(c, 8), _u32p(c, 12), inputViewportInPixelsX,
+                           inputViewportInPixelsY, inputSizeInPixelsX, inputSizeInPixelsY, outputSizeInPixelsX,
+                           outputSizeInPixelsY)
+    return c
+
+
+def FsrEasuConOffset(inputViewportInPixelsX, inputViewportInPixelsY, inputSizeInPixelsX, inputSizeInPixelsY,
+                     outputSizeInPixelsX, outputSizeInPixelsY, inputOffsetInPixelsX, inputOffsetInPixelsY):
+    """-> uint32[16] (ffx_fsr1.h:205-225)."""
+    c = np.zeros(16, np.uint32)
+    _lib.load().FsrEasuConOffset(_u32p(c, 0), _u32p(c, 4), _u32p(c, 8), _u32p(c, 12), inputViewportInPixelsX,
+                                 inputViewportInPixelsY, inputSizeInPixelsX, inputSizeInPixelsY, outputSizeInPixelsX,
+                                 outputSizeInPixelsY, inputOffsetInPixelsX, inputOffsetInPixelsY)
+    return c
+
+
+def FsrRcasCon(sharpness):
+    """-> uint32[4]; sharpness in stops, 0 = maximum (ffx_fsr1.h:662-672)."""
+    c = np.zeros(4, np.uint32)
+    _lib.load().FsrRcasCon(_u32p(c), sharpness)
+    return c
+
+
+def AU1_AH1_AF1(f):
+    return int(_lib.load().AU1_AH1_AF1(f))
+
+
+# --------------------------------------------------------------------------------------------------
+# images
+# --------------------------------------------------------------------------------------------------
+def image_of(t):
+    """fsr1_image descriptor of a CUDA torch tensor shaped (H,W,4) or (N,H,W,4), float16/float32.
+    Row and frame strides are honoured; the innermost (x, channel) dims must be dense."""
+    import torch
+    if not t.is_cuda:
+        raise Fsr1Error("image tensors must live on the GPU (got %s); there is no CPU path" % t.device)
+    if t.dim() == 3:
+        t = t.unsqueeze(0)
+    if t.dim() != 4 or t.shape[-1] != 4:
+        raise Fsr1Error("expected (N,H,W,4) RGBA, got %s" % (tuple(t.shape),))
+    if t.dtype == torch.float16:
+        fmt, es = FORMAT_RGBA16F, 2
+    elif t.dtype == torch.float32:
+        fmt, es = FORMAT_RGBA32F, 4
+    else:
+        raise Fsr1Error("unsupported dtype %s" % t.dtype)
+    n, h, w, _ = t.shape
+    sn, sh, sw, sc = t.stride()
+    if sc != 1 or sw != 4:
+        raise Fsr1Error("pixels must be RGBA-interleaved and dense along x")
+    return fsr1_image(t.data_ptr(), w, h, fmt, n, sh * es, sn * es if n > 1 else 0)
+
+
+def _stream_ptr(stream):
+    import torch
+    s = stream if stream is not None else torch.cuda.current_stream()
+    return ctypes.c_void_p(s.cuda_stream)
+
+
+def _con(c, n):
+    c = np.ascontiguousarray(c, dtype=np.uint32)
+    if c.size != n:
+        raise Fsr1Error("expected %d constant words, got %d" % (n, c.size))
+    return c
+
+
+# --------------------------------------------------------------------------------------------------
+# device passes
+# --------------------------------------------------------------------------------------------------
+def easu(src, dst, con=None, flags=0, stream=None):
+    """dst = EASU(src).  con defaults to FsrEasuCon(viewport = input size)."""
+    i, o = image_of(src), image_of(dst)
+    if con is None:
+        con = FsrEasuCon(i.width, i.height, i.width, i.height, o.width, o.height)
+    con = _con(con, 16)
+    _lib.check(_lib.load().fsr1_easu_dispatch(ctypes.byref(i), ctypes.byref(o), _u32p(con), flags, _stream_ptr(stream)))
+    return dst
+
+
+def rcas(src, dst, con=None, sharpness=0.25, flags=0, stream=None):
+    """dst = RCAS(src); con defaults to FsrRcasCon(sharpness)."""
+    i, o = image_of(src), image_of(dst)
+    con = _con(FsrRcasCon(sharpness) if con is None else con, 4)
+    _lib.check(_lib.load().fsr1_rcas_dispatch(ctypes.byref(i), ctypes.byref(o), _u32p(con), flags, _stream_ptr(stream)))
+    return dst
+
+
+def easu_rcas_fused(src, dst, easu_con=None, rcas_con=None, sharpness=0.25, flags=0, stream=None):
+    """dst = RCAS(EASU(src)) in one launch (intermediate kept in LDS)."""
+    i, o = image_of(src), image_of(dst)
+    if easu_con is None:
+        easu_con = FsrEasuCon(i.width, i.height, i.width, i.height, o.width, o.height)
+    easu_con = _con(easu_con, 16)
+    rcas_con = _con(FsrRcasCon(sharpness) if rcas_con is None else rcas_con, 4)
+    _lib.check(_lib.load().fsr1_easu_rcas_fused_dispatch(ctypes.byref(i), ctypes.byref(o), _u32p(easu_con), _u32p(rcas_con),
+                                                         flags, _stream_ptr(stream)))
+    return dst
+
+
+class State:
+    """The fields of the sample's `State` that FSR_Filter::Upscale reads (FSR_Filter.cpp:106-133)."""
+
+    def __init__(self, renderWidth, renderHeight, bUseRcas=True, rcasAttenuation=0.25, m_nUpscaleType=1):
+        self.renderWidth = renderWidth
+        self.renderHeight = renderHeight
+        self.bUseRcas = bUseRcas
+        self.rcasAttenuation = rcasAttenuation  # sample default, SampleRenderer.h:49
+        self.m_nUpscaleType = m_nUpscaleType    # 0 = bilinear in the sample (not part of this path)
+
+
+class FSR_Filter:
+    """Host glue with the reference's method names (sample/src/DX12/FSR_Filter.h:30-37).
+
+    OnCreate picks the arithmetic (slowFallback <-> fp32 FsrEasuF/FsrRcasF, the sample's
+    SAMPLE_SLOW_FALLBACK permutation; otherwise the packed-fp16 FsrEasuH/FsrRcasH permutation),
+    OnCreateWindowSizeDependentResources binds input/output and allocates the intermediary,
+    Upscale issues EASU -> RCAS (or EASU only) on a stream.
+    """
+
+    def __init__(self):
+        self._created = False
+        self._flags = 0
+        self.m_intermediary = None
+        self._input = None
+        self._output = None
+        self._hdr = False
+        self.fused = False
+
+    def OnCreate(self, slowFallback=True, exact=False, fused=False):
+        _lib.load()
+        self._flags = (FLAG_MATH_EXACT if exact else 0) if slowFallback else FLAG_MATH_PACKED_FP16
+        self.fused = fused
+        self._created = True
+
+    def OnCreateWindowSizeDependentResources(self, input, output, displayWidth, displayHeight, pState=None, hdr=False):
+        import torch
+        if not self._created:
+            raise Fsr1Error("OnCreate has not been called")
+        o = image_of(output)
+        if (o.width, o.height) != (displayWidth, displayHeight):
+            raise Fsr1Error("output tensor is %dx%d, display is %dx%d" % (o.width, o.height, displayWidth, displayHeight))
+        self._input, self._output, self._hdr = input, output, hdr
+        # FSR_Filter.cpp:72-73 creates the EASU->RCAS intermediary at display size; here it has the
+        # output's format (RGBA16F/RGBA32F) and batch size.
+        self.m_intermediary = None if self.fused else torch.empty_like(output)
+
+    def OnDestroyWindowSizeDependentResources(self):
+        self.m_intermediary = None
+        self._input = self._output = None
+
+    def OnDestroy(self):
+        self.OnDestroyWindowSizeDependentResources()
+        self._created = False
+
+    def Upscale(self, displayWidth, displayHeight, pState, hdr=None, stream=None):
+        if self._input is None:
+            raise Fsr1Error("OnCreateWindowSizeDependentResources has not been called")
+        if not pState.m_nUpscaleType:
+            raise Fsr1Error("m_nUpscaleType == 0 (bilinear) is outside the EASU+RCAS path")
+        hdr = self._hdr if hdr is None else hdr
+        p = fsr1_params(float(pState.renderWidth), float(pState.renderHeight), int(bool(pState.bUseRcas)),
+                        float(pState.rcasAttenuation), int(bool(hdr)), int(self.fused and pState.bUseRcas), self._flags)
+        i, o = image_of(self._input), image_of(self._output)
+        if (o.width, o.height) != (displayWidth, displayHeight):
+            raise Fsr1Error("display size changed: call OnCreateWindowSizeDependentResources again")
+        m = image_of(self.m_intermediary) if self.m_intermediary is not None else None
+        _lib.check(_lib.load().fsr1_upscale(ctypes.byref(i), ctypes.byref(m) if m is not None else None, ctypes.byref(o),
+                                           ctypes.byref(p), _stream_ptr(stream)))
+        return self._output
+
+
+class Timer:
+    """HIP-event stopwatch of the C ABI (fsr1_timer_*), recording on the stream the kernels use."""
+
+    def __init__(self):
+        self._h = ctypes.c_void_p()
+        _lib.check(_lib.load().fsr1_timer_create(ctypes.byref(self._h)))
+
+    def start(self, stream=None):
+        _lib.check(_lib.load().fsr1_timer_start(self._h, _stream_ptr(stream)))
+
+    def stop(self, stream=None):
+        _lib.check(_lib.load().fsr1_timer_stop(self._h, _stream_ptr(stream)))
+
+    def elapsed_ms(self):
+        ms = ctypes.c_float()
+        _lib.check(_lib.load().fsr1_timer_elapsed_ms(self._h, ctypes.byref(ms)))
+        return ms.value
+
+    def __del__(self):
+        try:
+            _lib.load().fsr1_timer_destroy(self._h)
+        except Exception:
+            pass

@@ -1,0 +1,262 @@
+// C ABI of the FSR 1.0 HIP path (include/fsr1_hip.h): argument checking, launch geometry, error
+// reporting.  The host logic mirrors FSR_Filter::Upscale (sample/src/DX12/FSR_Filter.cpp:101-141).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+#include "fsr1_device.h"
+
+namespace fsr1 {
+hipError_t easu_launch(const EasuArgs& a, int fmt, bool exact, hipStream_t stream);
+size_t easu_lds_bytes(int fmt, int fp_w, int fp_h);
+hipError_t rcas_launch(const RcasArgs& a, int fmt, bool exact, hipStream_t stream);
+hipError_t fused_launch(const FusedArgs& a, int fmt, bool exact, hipStream_t stream);
+size_t fused_lds_bytes(int fmt, int fp_w, int fp_h);
+hipError_t easu_h_launch(const EasuArgs& a, hipStream_t stream);
+hipError_t rcas_h_launch(const RcasArgs& a, hipStream_t stream);
+}  // namespace fsr1
+
+using namespace fsr1;
+
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof g_err, fmt, ap);
+  va_end(ap);
+  return code;
+}
+static int hip_fail(hipError_t e, const char* what) {
+  return fail(FSR1_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
+}
+
+static size_t pixel_bytes(int fmt) { return fmt == FSR1_FORMAT_RGBA16F ? 8 : 16; }
+
+static int check_image(const fsr1_image* im, const char* name, ImageView* v) {
+  if (!im) return fail(FSR1_ERR_INVALID_ARGUMENT, "%s: null image descriptor", name);
+  if (!im->data) return fail(FSR1_ERR_INVALID_ARGUMENT, "%s: null data pointer", name);
+  if (im->width <= 0 || im->height <= 0 || im->frames <= 0)
+    return fail(FSR1_ERR_INVALID_ARGUMENT, "%s: bad extent %dx%dx%d", name, im->width, im->height, im->frames);
+  if (im->format != FSR1_FORMAT_RGBA16F && im->format != FSR1_FORMAT_RGBA32F)
+    return fail(FSR1_ERR_UNSUPPORTED, "%s: unsupported format %d", name, im->format);
+  const size_t px = pixel_bytes(im->format);
+  const long long pitch = im->row_pitch_bytes ? im->row_pitch_bytes : (long long)im->width * (long long)px;
+  if (pitch < (long long)im->width * (long long)px || pitch % (long long)px)
+    return fail(FSR1_ERR_INVALID_ARGUMENT, "%s: row pitch %lld too small or not a multiple of the pixel size", name, pitch);
+  const long long fstride = im->frame_stride_bytes ? im->frame_stride_bytes : pitch * im->height;
+  if (im->frames > 1 && fstride < pitch * im->height)
+    return fail(FSR1_ERR_INVALID_ARGUMENT, "%s: frame stride %lld smaller than one frame", name, fstride);
+  if (((uintptr_t)im->data % px) || (fstride % (long long)px))
+    return fail(FSR1_ERR_INVALID_ARGUMENT, "%s: data pointer / frame stride not aligned to the pixel size", name);
+  v->base = static_cast<char*>(im->data);
+  v->width = im->width;
+  v->height = im->height;
+  v->pitch = pitch;
+  v->frame_stride = fstride;
+  return FSR1_OK;
+}
+
+static bool overlaps(const fsr1_image* a, const ImageView& va, const fsr1_image* b, const ImageView& vb) {
+  const char* a0 = va.base;
+  const char* a1 = va.base + va.frame_stride * (a->frames - 1) + va.pitch * a->height;
+  const char* b0 = vb.base;
+  const char* b1 = vb.base + vb.frame_stride * (b->frames - 1) + vb.pitch * b->height;
+  return a0 < b1 && b0 < a1;
+}
+
+// Largest number of input texels per axis any 64- (or 16-) pixel-wide output tile can touch:
+// fp(last) - fp(first) + 4 with fp(x) = floor(x*scale + bias); +1 for rounding slop.
+static int footprint_cap(int tile, float scale) {
+  if (!(scale > 0.0f) || !std::isfinite(scale)) return -1;
+  const double span = (double)(tile - 1) * (double)scale;
+  if (span > 4096.0) return -1;
+  return (int)std::floor(span) + 6;
+}
+
+static const uint32_t kKnownFlags = FSR1_FLAG_HDR_SQUARE | FSR1_FLAG_RCAS_DENOISE | FSR1_FLAG_RCAS_PASSTHROUGH_ALPHA |
+                                    FSR1_FLAG_MATH_EXACT | FSR1_FLAG_MATH_PACKED_FP16;
+
+static int check_flags(uint32_t flags) {
+  if (flags & ~kKnownFlags) return fail(FSR1_ERR_INVALID_ARGUMENT, "unknown flag bits 0x%x", flags & ~kKnownFlags);
+  if ((flags & FSR1_FLAG_MATH_EXACT) && (flags & FSR1_FLAG_MATH_PACKED_FP16))
+    return fail(FSR1_ERR_INVALID_ARGUMENT, "FSR1_FLAG_MATH_EXACT and FSR1_FLAG_MATH_PACKED_FP16 are exclusive");
+  return FSR1_OK;
+}
+
+extern "C" {
+
+const char* fsr1_last_error(void) { return g_err; }
+int fsr1_version(void) { return FSR1_HIP_VERSION; }
+
+int fsr1_device_count(void) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) return hip_fail(e, "hipGetDeviceCount");
+  return n;
+}
+
+int fsr1_easu_dispatch(const fsr1_image* in, const fsr1_image* out, const uint32_t con[16], uint32_t flags,
+                       void* stream) {
+  EasuArgs a;
+  int rc;
+  if ((rc = check_flags(flags))) return rc;
+  if ((rc = check_image(in, "easu input", &a.in))) return rc;
+  if ((rc = check_image(out, "easu output", &a.out))) return rc;
+  if (!con) return fail(FSR1_ERR_INVALID_ARGUMENT, "easu: null constants");
+  if (in->format != out->format) return fail(FSR1_ERR_UNSUPPORTED, "easu: input and output formats differ");
+  if (in->frames != out->frames) return fail(FSR1_ERR_INVALID_ARGUMENT, "easu: frame counts differ (%d vs %d)", in->frames, out->frames);
+  if (overlaps(in, a.in, out, a.out)) return fail(FSR1_ERR_INVALID_ARGUMENT, "easu: input and output overlap");
+  memcpy(a.con, con, sizeof a.con);
+  float sx, sy;
+  memcpy(&sx, &con[0], 4);
+  memcpy(&sy, &con[1], 4);
+  a.fp_w = footprint_cap(kTileW, sx);
+  a.fp_h = footprint_cap(kTileH, sy);
+  if (a.fp_w < 0 || a.fp_h < 0) return fail(FSR1_ERR_INVALID_ARGUMENT, "easu: scale constants con0.xy = (%g, %g) are not usable", sx, sy);
+  if (easu_lds_bytes(in->format, a.fp_w, a.fp_h) > 160 * 1024)
+    return fail(FSR1_ERR_UNSUPPORTED, "easu: input/output ratio (%g, %g) needs a %dx%d texel footprint per tile, beyond the LDS budget "
+                                      "(EASU is an upscaler; ratios up to ~3x minification are supported)", sx, sy, a.fp_w, a.fp_h);
+  a.tiles_x = (out->width + kTileW - 1) / kTileW;
+  a.tiles_y = (out->height + kTileH - 1) / kTileH;
+  a.frames = out->frames;
+  a.flags = flags;
+  hipError_t e;
+  if (flags & FSR1_FLAG_MATH_PACKED_FP16) {
+    if (in->format != FSR1_FORMAT_RGBA16F) return fail(FSR1_ERR_UNSUPPORTED, "easu: packed-fp16 math needs RGBA16F images");
+    e = easu_h_launch(a, static_cast<hipStream_t>(stream));
+  } else {
+    e = easu_launch(a, in->format, (flags & FSR1_FLAG_MATH_EXACT) != 0, static_cast<hipStream_t>(stream));
+  }
+  if (e != hipSuccess) return hip_fail(e, "easu launch");
+  return FSR1_OK;
+}
+
+int fsr1_rcas_dispatch(const fsr1_image* in, const fsr1_image* out, const uint32_t con[4], uint32_t flags, void* stream) {
+  RcasArgs a;
+  int rc;
+  if ((rc = check_flags(flags))) return rc;
+  if ((rc = check_image(in, "rcas input", &a.in))) return rc;
+  if ((rc = check_image(out, "rcas output", &a.out))) return rc;
+  if (!con) return fail(FSR1_ERR_INVALID_ARGUMENT, "rcas: null constants");
+  if (in->format != out->format) return fail(FSR1_ERR_UNSUPPORTED, "rcas: input and output formats differ");
+  if (in->width != out->width || in->height != out->height || in->frames != out->frames)
+    return fail(FSR1_ERR_INVALID_ARGUMENT, "rcas: input %dx%dx%d and output %dx%dx%d extents differ", in->width, in->height,
+                in->frames, out->width, out->height, out->frames);
+  if (overlaps(in, a.in, out, a.out)) return fail(FSR1_ERR_INVALID_ARGUMENT, "rcas: input and output overlap (RCAS cannot run in place)");
+  memcpy(a.con, con, sizeof a.con);
+  a.tiles_x = (out->width + kTileW - 1) / kTileW;
+  a.tiles_y = (out->height + kTileH - 1) / kTileH;
+  a.frames = out->frames;
+  a.flags = flags;
+  hipError_t e;
+  if (flags & FSR1_FLAG_MATH_PACKED_FP16) {
+    if (in->format != FSR1_FORMAT_RGBA16F) return fail(FSR1_ERR_UNSUPPORTED, "rcas: packed-fp16 math needs RGBA16F images");
+    e = rcas_h_launch(a, static_cast<hipStream_t>(stream));
+  } else {
+    e = rcas_launch(a, in->format, (flags & FSR1_FLAG_MATH_EXACT) != 0, static_cast<hipStream_t>(stream));
+  }
+  if (e != hipSuccess) return hip_fail(e, "rcas launch");
+  return FSR1_OK;
+}
+
+int fsr1_easu_rcas_fused_dispatch(const fsr1_image* in, const fsr1_image* out, const uint32_t easu_con[16],
+                                  const uint32_t rcas_con[4], uint32_t flags, void* stream) {
+  FusedArgs a;
+  int rc;
+  if ((rc = check_flags(flags))) return rc;
+  if ((rc = check_image(in, "fused input", &a.in))) return rc;
+  if ((rc = check_image(out, "fused output", &a.out))) return rc;
+  if (!easu_con || !rcas_con) return fail(FSR1_ERR_INVALID_ARGUMENT, "fused: null constants");
+  if (in->format != out->format) return fail(FSR1_ERR_UNSUPPORTED, "fused: input and output formats differ");
+  if (in->frames != out->frames) return fail(FSR1_ERR_INVALID_ARGUMENT, "fused: frame counts differ (%d vs %d)", in->frames, out->frames);
+  if (overlaps(in, a.in, out, a.out)) return fail(FSR1_ERR_INVALID_ARGUMENT, "fused: input and output overlap");
+  if (flags & FSR1_FLAG_MATH_PACKED_FP16) return fail(FSR1_ERR_UNSUPPORTED, "fused: packed-fp16 math is not available in the fused kernel");
+  memcpy(a.easu_con, easu_con, sizeof a.easu_con);
+  memcpy(a.rcas_con, rcas_con, sizeof a.rcas_con);
+  float sx, sy;
+  memcpy(&sx, &easu_con[0], 4);
+  memcpy(&sy, &easu_con[1], 4);
+  a.fp_w = footprint_cap(kTileW + 2, sx);
+  a.fp_h = footprint_cap(kTileH + 2, sy);
+  if (a.fp_w < 0 || a.fp_h < 0) return fail(FSR1_ERR_INVALID_ARGUMENT, "fused: scale constants con0.xy = (%g, %g) are not usable", sx, sy);
+  if (fused_lds_bytes(in->format, a.fp_w, a.fp_h) > 160 * 1024)
+    return fail(FSR1_ERR_UNSUPPORTED, "fused: input/output ratio (%g, %g) needs more LDS than a CU has", sx, sy);
+  a.tiles_x = (out->width + kTileW - 1) / kTileW;
+  a.tiles_y = (out->height + kTileH - 1) / kTileH;
+  a.frames = out->frames;
+  a.flags = flags;
+  hipError_t e = fused_launch(a, in->format, (flags & FSR1_FLAG_MATH_EXACT) != 0, static_cast<hipStream_t>(stream));
+  if (e != hipSuccess) return hip_fail(e, "fused launch");
+  return FSR1_OK;
+}
+
+// FSR_Filter::Upscale, sample/src/DX12/FSR_Filter.cpp:101-141.
+int fsr1_upscale(const fsr1_image* in, const fsr1_image* intermediary, const fsr1_image* out, const fsr1_params* p,
+                 void* stream) {
+  if (!in || !out || !p) return fail(FSR1_ERR_INVALID_ARGUMENT, "upscale: null argument");
+  uint32_t easu_con[16], rcas_con[4];
+  // :106 — viewport == input resource size == (renderWidth, renderHeight); output = display size
+  FsrEasuCon(easu_con, easu_con + 4, easu_con + 8, easu_con + 12, p->render_width, p->render_height, p->render_width,
+             p->render_height, (float)out->width, (float)out->height);
+  const uint32_t math = p->flags & (FSR1_FLAG_MATH_EXACT | FSR1_FLAG_MATH_PACKED_FP16);
+  const uint32_t rcas_opts = p->flags & (FSR1_FLAG_RCAS_DENOISE | FSR1_FLAG_RCAS_PASSTHROUGH_ALPHA);
+  if (p->flags & ~(math | rcas_opts)) return fail(FSR1_ERR_INVALID_ARGUMENT, "upscale: params.flags may only hold MATH_* and RCAS_* bits");
+  if (!p->use_rcas) {
+    // :107 Sample.x = hdr && !bUseRcas ; :140 EASU straight into the output
+    return fsr1_easu_dispatch(in, out, easu_con, math | (p->hdr ? FSR1_FLAG_HDR_SQUARE : 0u), stream);
+  }
+  FsrRcasCon(rcas_con, p->rcas_attenuation);  // :124
+  const uint32_t rcas_flags = math | rcas_opts | (p->hdr ? FSR1_FLAG_HDR_SQUARE : 0u);  // :125 Sample.x = hdr
+  if (p->fused) return fsr1_easu_rcas_fused_dispatch(in, out, easu_con, rcas_con, rcas_flags, stream);
+  if (!intermediary) return fail(FSR1_ERR_INVALID_ARGUMENT, "upscale: two-pass EASU+RCAS needs an intermediary image");
+  int rc = fsr1_easu_dispatch(in, intermediary, easu_con, math, stream);  // :121 (Sample.x = 0 when RCAS follows)
+  if (rc) return rc;
+  // :130 the UAV->SRV barrier is stream order here
+  return fsr1_rcas_dispatch(intermediary, out, rcas_con, rcas_flags, stream);  // :131
+}
+
+// ---- HIP-event stopwatch ----
+struct fsr1_timer {
+  hipEvent_t start, stop;
+};
+
+int fsr1_timer_create(void** timer) {
+  if (!timer) return fail(FSR1_ERR_INVALID_ARGUMENT, "timer_create: null");
+  fsr1_timer* t = new fsr1_timer;
+  hipError_t e = hipEventCreate(&t->start);
+  if (e == hipSuccess) e = hipEventCreate(&t->stop);
+  if (e != hipSuccess) { delete t; return hip_fail(e, "hipEventCreate"); }
+  *timer = t;
+  return FSR1_OK;
+}
+int fsr1_timer_start(void* timer, void* stream) {
+  if (!timer) return fail(FSR1_ERR_INVALID_ARGUMENT, "timer_start: null");
+  hipError_t e = hipEventRecord(static_cast<fsr1_timer*>(timer)->start, static_cast<hipStream_t>(stream));
+  return e == hipSuccess ? FSR1_OK : hip_fail(e, "hipEventRecord");
+}
+int fsr1_timer_stop(void* timer, void* stream) {
+  if (!timer) return fail(FSR1_ERR_INVALID_ARGUMENT, "timer_stop: null");
+  hipError_t e = hipEventRecord(static_cast<fsr1_timer*>(timer)->stop, static_cast<hipStream_t>(stream));
+  return e == hipSuccess ? FSR1_OK : hip_fail(e, "hipEventRecord");
+}
+int fsr1_timer_elapsed_ms(void* timer, float* ms) {
+  if (!timer || !ms) return fail(FSR1_ERR_INVALID_ARGUMENT, "timer_elapsed_ms: null");
+  fsr1_timer* t = static_cast<fsr1_timer*>(timer);
+  hipError_t e = hipEventSynchronize(t->stop);
+  if (e == hipSuccess) e = hipEventElapsedTime(ms, t->start, t->stop);
+  return e == hipSuccess ? FSR1_OK : hip_fail(e, "hipEventElapsedTime");
+}
+int fsr1_timer_destroy(void* timer) {
+  if (!timer) return FSR1_OK;
+  fsr1_timer* t = static_cast<fsr1_timer*>(timer);
+  (void)hipEventDestroy(t->start);
+  (void)hipEventDestroy(t->stop);
+  delete t;
+  return FSR1_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,106 @@
+// Shared device-side pieces of the FSR 1.0 HIP kernels (gfx950 only).
+//
+// The translation units including this header are compiled with -ffp-contract=off: every
+// fused multiply-add in the kernels is an explicit fmaf()/__builtin_elementwise_fma, so the
+// "EXACT" variants keep the reference's operation order and rounding (ffx_fsr1.h), and the
+// default variants fuse only where the filter is continuous in its inputs.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "fsr1_hip.h"
+
+namespace fsr1 {
+
+typedef _Float16 half_t;
+typedef half_t half2_t __attribute__((ext_vector_type(2)));
+typedef half_t half4_t __attribute__((ext_vector_type(4)));
+typedef float float2_t __attribute__((ext_vector_type(2)));
+typedef float float4_t __attribute__((ext_vector_type(4)));
+
+// Output tile of one 256-thread workgroup (4 waves): 64 x 16 pixels, each wave owns 4 rows, a
+// lane owns one column -> every global store instruction writes 64 consecutive pixels.
+constexpr int kTileW = 64;
+constexpr int kTileH = 16;
+constexpr int kThreads = 256;
+constexpr int kXcds = 8;  // MI355X: 8 XCDs, workgroup b is dispatched to XCD b % 8
+
+struct ImageView {
+  char* base;
+  int width, height;
+  long long pitch;         // bytes between rows
+  long long frame_stride;  // bytes between frames
+};
+
+struct EasuArgs {
+  ImageView in, out;
+  uint32_t con[16];
+  int tiles_x, tiles_y, frames;
+  int fp_w, fp_h;  // LDS footprint capacity (texels) per tile, >= the largest footprint of any tile
+  uint32_t flags;
+};
+
+struct RcasArgs {
+  ImageView in, out;
+  uint32_t con[4];
+  int tiles_x, tiles_y, frames;
+  uint32_t flags;
+};
+
+struct FusedArgs {
+  ImageView in, out;
+  uint32_t easu_con[16];
+  uint32_t rcas_con[4];
+  int tiles_x, tiles_y, frames;
+  int fp_w, fp_h;
+  uint32_t flags;
+};
+
+__device__ __forceinline__ float as_f32(uint32_t u) { return __uint_as_float(u); }
+__device__ __forceinline__ uint32_t as_u32(float f) { return __float_as_uint(f); }
+
+// ffx_a.h:1843-1845 — integer-trick approximations; one v_sub_u32 (+ one shift) each.  They are part
+// of the algorithm's definition (results differ from v_rcp_f32/v_rsq_f32), so they stay as they are.
+__device__ __forceinline__ float APrxLoRcpF1(float a) { return as_f32(0x7ef07ebbu - as_u32(a)); }
+__device__ __forceinline__ float APrxLoRsqF1(float a) { return as_f32(0x5f347d74u - (as_u32(a) >> 1)); }
+template <bool EXACT>
+__device__ __forceinline__ float APrxMedRcpF1(float a) {
+  float b = as_f32(0x7ef19fffu - as_u32(a));
+  return EXACT ? b * (-b * a + 2.0f) : b * fmaf(-b, a, 2.0f);
+}
+// min/max with IEEE minNum/maxNum semantics = v_min_f32/v_max_f32 in IEEE mode (fminf/fmaxf lower to them).
+__device__ __forceinline__ float min3f(float a, float b, float c) { return fminf(a, fminf(b, c)); }  // v_min3_f32
+__device__ __forceinline__ float max3f(float a, float b, float c) { return fmaxf(a, fmaxf(b, c)); }  // v_max3_f32
+__device__ __forceinline__ float sat(float x) { return fminf(fmaxf(x, 0.0f), 1.0f); }               // clamp modifier / v_med3
+
+// a*b+c : two roundings when EXACT (reference order), one (v_fma_f32 / v_fma_mix_f32) otherwise.
+template <bool EXACT>
+__device__ __forceinline__ float mad(float a, float b, float c) { return EXACT ? a * b + c : fmaf(a, b, c); }
+
+// XCD-aware workgroup -> tile mapping.  Consecutive workgroup ids round-robin over the 8 XCDs
+// (each with a private 4 MiB L2), so the ids that land on one XCD are given one contiguous range
+// of tiles: neighbouring tiles, which share their input aprons, then share an L2.
+__device__ __forceinline__ int xcd_swizzle(int b, int n) {
+  const int q = n / kXcds, r = n % kXcds;
+  const int xcd = b % kXcds, idx = b / kXcds;
+  return xcd * q + (xcd < r ? xcd : r) + idx;
+}
+
+// RTNE float -> binary16 (v_cvt_f16_f32 under the default rounding mode; never cvt_pkrtz).
+__device__ __forceinline__ half_t to_half(float f) { return (half_t)f; }
+
+template <int FMT> struct Pixel;  // FMT = fsr1_format
+template <> struct Pixel<FSR1_FORMAT_RGBA16F> {
+  typedef half4_t T;
+  static __device__ __forceinline__ float4_t load(const T& p) { return float4_t{(float)p.x, (float)p.y, (float)p.z, (float)p.w}; }
+  static __device__ __forceinline__ T store(float r, float g, float b, float a) { return T{to_half(r), to_half(g), to_half(b), to_half(a)}; }
+  static __device__ __forceinline__ T zero() { return T{(half_t)0, (half_t)0, (half_t)0, (half_t)0}; }
+};
+template <> struct Pixel<FSR1_FORMAT_RGBA32F> {
+  typedef float4_t T;
+  static __device__ __forceinline__ float4_t load(const T& p) { return p; }
+  static __device__ __forceinline__ T store(float r, float g, float b, float a) { return T{r, g, b, a}; }
+  static __device__ __forceinline__ T zero() { return T{0.f, 0.f, 0.f, 0.f}; }
+};
+
+}  // namespace fsr1

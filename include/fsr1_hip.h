@@ -1,0 +1,157 @@
+/*
+ * fsr1_hip.h — C ABI of the MI355X-native FSR 1.0 hot path (EASU upsample + RCAS sharpen).
+ *
+ * Drop-in boundary for the reference's source-level operator set:
+ *   host   : FsrEasuCon / FsrEasuConOffset / FsrRcasCon — same spellings, argument order and
+ *            bit-exact outputs as the A_CPU build of ffx-fsr/ffx_fsr1.h:156-225, :662-672.
+ *   device : fsr1_easu_dispatch / fsr1_rcas_dispatch / fsr1_easu_rcas_fused_dispatch replace the
+ *            compute dispatches of sample/src/DX12/FSR_Pass.hlsl:106-118 (mainCS -> CurrFilter ->
+ *            FsrEasuF|H / FsrRcasF|H) issued by FSR_Filter::Upscale
+ *            (sample/src/DX12/FSR_Filter.cpp:101-141); fsr1_upscale is Upscale() itself.
+ *
+ * Plain pointers and sizes only; device memory is caller-owned; every dispatch is asynchronous on
+ * the HIP stream passed as an opaque void* (NULL = the default stream); no hidden global state
+ * except a per-thread last-error string.  All functions returning int return 0 on success and a
+ * negative fsr1_status on failure.
+ */
+#ifndef FSR1_HIP_H
+#define FSR1_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FSR1_HIP_VERSION 100 /* 1.0.0 */
+
+/* ------------------------------------------------------------------------------------------------
+ * Constant setup (host, pure, re-entrant).  Replaces ffx_fsr1.h:156-202, :205-225, :662-672.
+ * Sizes are passed as floats exactly like the reference.  con0..con3 / con are caller-owned
+ * uint32_t[4] each.
+ * ---------------------------------------------------------------------------------------------- */
+void FsrEasuCon(uint32_t* con0, uint32_t* con1, uint32_t* con2, uint32_t* con3,
+                float inputViewportInPixelsX, float inputViewportInPixelsY,
+                float inputSizeInPixelsX, float inputSizeInPixelsY,
+                float outputSizeInPixelsX, float outputSizeInPixelsY);
+
+void FsrEasuConOffset(uint32_t* con0, uint32_t* con1, uint32_t* con2, uint32_t* con3,
+                      float inputViewportInPixelsX, float inputViewportInPixelsY,
+                      float inputSizeInPixelsX, float inputSizeInPixelsY,
+                      float outputSizeInPixelsX, float outputSizeInPixelsY,
+                      float inputOffsetInPixelsX, float inputOffsetInPixelsY);
+
+/* sharpness in stops: 0.0 = maximum, N>0 halves the sharpening N times (ffx_fsr1.h:645). */
+void FsrRcasCon(uint32_t* con, float sharpness);
+
+/* ffx_a.h:482-549 — float -> half by truncation, +-inf/NaN -> +-65504; used by FsrRcasCon. */
+uint32_t AU1_AH1_AF1(float f);
+
+/* ------------------------------------------------------------------------------------------------
+ * Images.  Pixels are RGBA interleaved; rows are row_pitch_bytes apart, frames (independent
+ * images of one batch, processed by one launch) frame_stride_bytes apart.
+ * ---------------------------------------------------------------------------------------------- */
+typedef enum fsr1_format {
+  FSR1_FORMAT_RGBA16F = 0, /* 8 B/pixel; the view type the reference shader declares
+                              (Texture2D<AH4> / RWTexture2D<AH4>, FSR_Pass.hlsl:51-52) */
+  FSR1_FORMAT_RGBA32F = 1  /* 16 B/pixel; the SAMPLE_SLOW_FALLBACK view (FSR_Pass.hlsl:34-36) */
+} fsr1_format;
+
+typedef struct fsr1_image {
+  void* data;                 /* device pointer */
+  int32_t width, height;      /* in pixels */
+  int32_t format;             /* fsr1_format */
+  int32_t frames;             /* >= 1 */
+  int64_t row_pitch_bytes;    /* 0 = tightly packed */
+  int64_t frame_stride_bytes; /* 0 = tightly packed */
+} fsr1_image;
+
+/* ------------------------------------------------------------------------------------------------
+ * Dispatch flags
+ * ---------------------------------------------------------------------------------------------- */
+enum {
+  /* `if (Sample.x == 1) c *= c;` after the filter (FSR_Pass.hlsl:78-79, :92-93): HDR gamma2 -> linear */
+  FSR1_FLAG_HDR_SQUARE = 1u << 0,
+  /* ffx_fsr1.h:651 FSR_RCAS_DENOISE */
+  FSR1_FLAG_RCAS_DENOISE = 1u << 1,
+  /* ffx_fsr1.h:648 FSR_RCAS_PASSTHROUGH_ALPHA (otherwise alpha is written as 1, FSR_Pass.hlsl:80) */
+  FSR1_FLAG_RCAS_PASSTHROUGH_ALPHA = 1u << 2,
+  /* Arithmetic selection.  Default (neither bit): fp32 arithmetic with FMA contraction in the
+   * continuous part of the filter — the FsrEasuF / FsrRcasF entry points ("F" parity class:
+   * within 1 binary16 ULP of the reference's CPU-evaluated F path).
+   * EXACT: fp32 arithmetic in the reference's exact operation order, no contraction, IEEE
+   * division — bit-identical (fp32) to the CPU-evaluated FsrEasuF / FsrRcasF.
+   * PACKED_FP16: the FsrEasuH / FsrRcasH entry points — packed binary16 arithmetic
+   * (v_pk_*_f16), parity class "H" (vs the reference's CPU-evaluated H path). */
+  FSR1_FLAG_MATH_EXACT = 1u << 4,
+  FSR1_FLAG_MATH_PACKED_FP16 = 1u << 5
+};
+
+typedef enum fsr1_status {
+  FSR1_OK = 0,
+  FSR1_ERR_INVALID_ARGUMENT = -1,
+  FSR1_ERR_UNSUPPORTED = -2,
+  FSR1_ERR_HIP = -3
+} fsr1_status;
+
+/* ------------------------------------------------------------------------------------------------
+ * Device passes
+ * ---------------------------------------------------------------------------------------------- */
+
+/* EASU: out[frame] = FsrEasuF|H(in[frame]) for every output pixel; con = con0|con1|con2|con3
+ * (16 words) from FsrEasuCon / FsrEasuConOffset.  Taps are clamped to the edge of the input
+ * *resource* (in->width x in->height), like the CLAMP sampler (FSR_Filter.cpp:48-53). */
+int fsr1_easu_dispatch(const fsr1_image* in, const fsr1_image* out, const uint32_t con[16], uint32_t flags,
+                       void* stream);
+
+/* RCAS: in and out have the same size; loads outside the image return 0 (D3D Load, FSR_Pass.hlsl:45,61).
+ * con = the 4 words from FsrRcasCon.  in and out must not alias. */
+int fsr1_rcas_dispatch(const fsr1_image* in, const fsr1_image* out, const uint32_t con[4], uint32_t flags,
+                       void* stream);
+
+/* EASU -> RCAS in one launch: the EASU result of each output tile (+1 pixel apron) is kept in LDS,
+ * rounded to the intermediate format the two-pass pipeline would have stored (binary16 for
+ * RGBA16F images), and sharpened from there — bit-identical to the two dispatches above with an
+ * RGBA16F/RGBA32F intermediary of out's format, without its 2 x out bytes of HBM traffic. */
+int fsr1_easu_rcas_fused_dispatch(const fsr1_image* in, const fsr1_image* out, const uint32_t easu_con[16],
+                                  const uint32_t rcas_con[4], uint32_t flags, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * FSR_Filter::Upscale (sample/src/DX12/FSR_Filter.cpp:101-141) as one call.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct fsr1_params {
+  float render_width, render_height;   /* pState->renderWidth/Height: viewport == input resource size */
+  int32_t use_rcas;                    /* pState->bUseRcas */
+  float rcas_attenuation;              /* pState->rcasAttenuation, stops (sample default 0.25, SampleRenderer.h:49) */
+  int32_t hdr;                         /* `hdr` argument of Upscale: Sample.x = hdr && !use_rcas for EASU, hdr for RCAS */
+  int32_t fused;                       /* 1: single fused launch instead of EASU + RCAS (needs use_rcas) */
+  uint32_t flags;                      /* FSR1_FLAG_MATH_* and FSR1_FLAG_RCAS_DENOISE / _PASSTHROUGH_ALPHA */
+} fsr1_params;
+
+/* in -> (intermediary) -> out.  `intermediary` may be NULL when use_rcas == 0 or fused == 1. */
+int fsr1_upscale(const fsr1_image* in, const fsr1_image* intermediary, const fsr1_image* out,
+                 const fsr1_params* params, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Diagnostics
+ * ---------------------------------------------------------------------------------------------- */
+/* Thread-local message of the last failing call on this thread ("" if none). */
+const char* fsr1_last_error(void);
+int fsr1_version(void);
+/* Number of HIP devices visible, or a negative fsr1_status. */
+int fsr1_device_count(void);
+
+/* HIP-event stopwatch on a caller stream (used by the bench so that kernel time is measured on the
+ * very stream the kernels run on).  Handles are opaque. */
+int fsr1_timer_create(void** timer);
+int fsr1_timer_start(void* timer, void* stream);
+int fsr1_timer_stop(void* timer, void* stream);
+/* Blocks until the stop event completed; returns elapsed milliseconds through *ms. */
+int fsr1_timer_elapsed_ms(void* timer, float* ms);
+int fsr1_timer_destroy(void* timer);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FSR1_HIP_H */

@@ -1,0 +1,74 @@
+"""The C-ABI library loads, exports every symbol include/fsr1_hip.h declares, and validates its
+arguments — no compute calls, runs without a GPU."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, "include", "fsr1_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = re.findall(r"^\s*(?:const\s+)?(?:void|int|uint32_t|char\s*\*|const char\s*\*)\s*\*?\s*([A-Za-z_][A-Za-z0-9_]*)\s*\(", text, flags=re.M)
+    return sorted(set(names))
+
+
+def test_header_symbols_are_exported(fsr):
+    lib = ctypes.CDLL(fsr._lib.LIB_PATH)
+    syms = header_symbols()
+    assert {"FsrEasuCon", "FsrEasuConOffset", "FsrRcasCon", "fsr1_easu_dispatch", "fsr1_rcas_dispatch",
+            "fsr1_easu_rcas_fused_dispatch", "fsr1_upscale", "fsr1_last_error"} <= set(syms)
+    for s in syms:
+        assert hasattr(lib, s), "include/fsr1_hip.h declares %s but libfsr1_hip.so does not export it" % s
+    assert set(syms) == set(fsr._lib.SYMBOLS), "python prototypes and header disagree"
+
+
+def test_version(fsr):
+    assert fsr.load().fsr1_version() == 100
+
+
+def test_argument_validation(fsr):
+    lib = fsr.load()
+    img = fsr.fsr1_image(0, 16, 16, 0, 1, 0, 0)
+    con = np.zeros(16, np.uint32)
+    p = con.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32))
+    assert lib.fsr1_easu_dispatch(None, None, p, 0, None) == -1
+    assert b"null" in lib.fsr1_last_error()
+    assert lib.fsr1_easu_dispatch(ctypes.byref(img), ctypes.byref(img), p, 0, None) == -1  # null data
+    bad = fsr.fsr1_image(0x1000, 16, 16, 7, 1, 0, 0)
+    assert lib.fsr1_easu_dispatch(ctypes.byref(bad), ctypes.byref(bad), p, 0, None) == -2  # unsupported format
+    ok = fsr.fsr1_image(0x1000, 16, 16, 0, 1, 0, 0)
+    ok2 = fsr.fsr1_image(0x100000, 32, 32, 0, 1, 0, 0)
+    assert lib.fsr1_easu_dispatch(ctypes.byref(ok), ctypes.byref(ok2), p, 1 << 9, None) == -1  # unknown flag
+    assert lib.fsr1_easu_dispatch(ctypes.byref(ok), ctypes.byref(ok2), p, (1 << 4) | (1 << 5), None) == -1  # exclusive
+    assert lib.fsr1_easu_dispatch(ctypes.byref(ok), ctypes.byref(ok), p, 0, None) == -1  # aliasing
+    assert b"overlap" in lib.fsr1_last_error()
+    assert lib.fsr1_easu_dispatch(ctypes.byref(ok), ctypes.byref(ok2), p, 0, None) == -1  # con0 scale = 0
+    assert lib.fsr1_rcas_dispatch(ctypes.byref(ok), ctypes.byref(ok2), p, 0, None) == -1  # extents differ
+    short = fsr.fsr1_image(0x1000, 16, 16, 0, 1, 64, 0)
+    assert lib.fsr1_rcas_dispatch(ctypes.byref(short), ctypes.byref(ok2), p, 0, None) == -1  # pitch < row
+    odd = fsr.fsr1_image(0x1004, 16, 16, 0, 1, 0, 0)
+    assert lib.fsr1_rcas_dispatch(ctypes.byref(odd), ctypes.byref(ok2), p, 0, None) == -1  # misaligned
+
+
+def test_no_cpu_fallback(fsr):
+    """Host tensors are refused: the product has no CPU path."""
+    import torch
+    with pytest.raises(fsr.Fsr1Error):
+        fsr.image_of(torch.zeros(4, 4, 4, dtype=torch.float16))
+
+
+def test_product_does_not_link_the_oracle(fsr):
+    """Nothing under the package or the library refers to oracle/."""
+    blob = open(fsr._lib.LIB_PATH, "rb").read()
+    assert b"oracle_" not in blob and b"ref_easu" not in blob
+    pkg_dir = os.path.dirname(fsr._lib.LIB_PATH)
+    for dirpath, _, files in os.walk(pkg_dir):
+        for f in files:
+            if f.endswith((".py", ".hip", ".c", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "cpu_oracle" not in src and "libfsr1_oracle" not in src and "libfsr1_ref" not in src, f

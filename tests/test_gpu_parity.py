@@ -1,0 +1,303 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle, on a real MI355X.
+
+Parity classes (DESIGN.md "Numerics"):
+  EXACT   FSR1_FLAG_MATH_EXACT: bit-identical to the CPU-evaluated FsrEasuF / FsrRcasF — compared as raw
+          fp32 bits for RGBA32F images, and as binary16 bits (oracle rounded RTNE) for RGBA16F.
+  F       default arithmetic: every value within 1 binary16 ULP of the oracle (tolerance stated by
+          BASELINE.json's north_star), and at least 99.5 % of the values bit-equal.
+"""
+import importlib
+
+import numpy as np
+import pytest
+
+from conftest import PIXEL_CASES, load_golden
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+frames = importlib.import_module("fidelityfx-fsr_amd.frames")
+
+ULP_TOL = 1            # binary16 ULPs, north_star: "within 1 ULP fp16"
+MIN_EXACT_FRACTION = 0.995
+
+
+def dev(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    return t if dtype is None else t.to(dtype)
+
+
+def host(t):
+    torch.cuda.synchronize()
+    return t.detach().cpu().numpy()
+
+
+def h16bits(a):
+    return np.ascontiguousarray(a).astype(np.float16).view(np.uint16)
+
+
+def assert_exact16(gpu_f16, oracle_f32, what=""):
+    g, o = h16bits(gpu_f16), h16bits(oracle_f32)
+    bad = g != o
+    assert not bad.any(), "%s: %d of %d binary16 values differ (first at %s)" % (what, bad.sum(), bad.size, np.argwhere(bad)[:3].tolist())
+
+
+def assert_exact32(gpu_f32, oracle_f32, what=""):
+    g = np.ascontiguousarray(gpu_f32, np.float32).view(np.uint32)
+    o = np.ascontiguousarray(oracle_f32, np.float32).view(np.uint32)
+    bad = (g != o) & ~(np.isnan(gpu_f32) & np.isnan(oracle_f32))
+    assert not bad.any(), "%s: %d of %d fp32 values differ" % (what, bad.sum(), bad.size)
+
+
+def assert_f_class(gpu, oracle_f32, what=""):
+    import cpu_oracle
+    d = cpu_oracle.half_ulp_diff(np.asarray(gpu, np.float32), oracle_f32)
+    assert d.max() <= ULP_TOL, "%s: max %d binary16 ULP (tolerance %d)" % (what, d.max(), ULP_TOL)
+    frac = float((d == 0).mean())
+    assert frac >= MIN_EXACT_FRACTION, "%s: only %.4f of values bit-equal" % (what, frac)
+    assert not np.isnan(np.asarray(gpu, np.float32)).any()
+
+
+# ------------------------------------------------------------------------------------------------
+# golden fixtures (generated from the reference headers compiled verbatim)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", PIXEL_CASES)
+def test_easu_golden(fsr, name):
+    g = load_golden(name)
+    oh, ow = g["easu_f"].shape[:2]
+    src16 = dev(g["input"])
+    out16 = torch.zeros(oh, ow, 4, dtype=torch.float16, device="cuda")
+    fsr.easu(src16, out16, con=g["con"], flags=fsr.FLAG_MATH_EXACT)
+    assert_exact16(host(out16), g["easu_f"], name + " easu EXACT f16")
+    out16.zero_()
+    fsr.easu(src16, out16, con=g["con"])
+    assert_f_class(host(out16), g["easu_f"], name + " easu F f16")
+    src32 = src16.float()
+    out32 = torch.zeros(oh, ow, 4, dtype=torch.float32, device="cuda")
+    fsr.easu(src32, out32, con=g["con"], flags=fsr.FLAG_MATH_EXACT)
+    assert_exact32(host(out32), g["easu_f"], name + " easu EXACT f32")
+    out32.zero_()
+    fsr.easu(src32, out32, con=g["con"])
+    assert_f_class(host(out32), g["easu_f"], name + " easu F f32")
+    out32.zero_()
+    fsr.easu(src32, out32, con=g["con"], flags=fsr.FLAG_MATH_EXACT | fsr.FLAG_HDR_SQUARE)
+    assert_exact32(host(out32), g["easu_f_hdr"], name + " easu EXACT f32 hdr")
+
+
+@pytest.mark.parametrize("name", PIXEL_CASES)
+def test_rcas_golden(fsr, name):
+    g = load_golden(name)
+    mid16 = dev(g["mid"])
+    out16 = torch.zeros_like(mid16)
+    flagmap = {0: 0, 1: fsr.FLAG_RCAS_DENOISE, 2: fsr.FLAG_RCAS_PASSTHROUGH_ALPHA,
+               3: fsr.FLAG_RCAS_DENOISE | fsr.FLAG_RCAS_PASSTHROUGH_ALPHA}
+    for fl, bits in flagmap.items():
+        want = g["rcas_f_%d" % fl]
+        out16.zero_()
+        fsr.rcas(mid16, out16, con=g["rcas_con"], flags=bits | fsr.FLAG_MATH_EXACT)
+        assert_exact16(host(out16), want, "%s rcas EXACT f16 flags %d" % (name, fl))
+        out16.zero_()
+        fsr.rcas(mid16, out16, con=g["rcas_con"], flags=bits)
+        assert_f_class(host(out16), want, "%s rcas F f16 flags %d" % (name, fl))
+        mid32 = mid16.float()
+        out32 = torch.zeros_like(mid32)
+        fsr.rcas(mid32, out32, con=g["rcas_con"], flags=bits | fsr.FLAG_MATH_EXACT)
+        assert_exact32(host(out32), want, "%s rcas EXACT f32 flags %d" % (name, fl))
+    out32.zero_()
+    fsr.rcas(mid16.float(), out32, con=g["rcas_con"], flags=fsr.FLAG_HDR_SQUARE | fsr.FLAG_MATH_EXACT)
+    assert_exact32(host(out32), g["rcas_f_hdr"], name + " rcas EXACT f32 hdr")
+
+
+def test_survey_kat_b2_on_gpu(fsr):
+    """SURVEY.md Appendix B.2 frame, fp32 I/O, intermediate not rounded: bit-exact chain."""
+    g = load_golden("kat_b2")
+    src = dev(g["input"])
+    mid = torch.zeros(72, 128, 4, dtype=torch.float32, device="cuda")
+    out = torch.zeros_like(mid)
+    fsr.easu(src, mid, con=g["con"], flags=fsr.FLAG_MATH_EXACT)
+    fsr.rcas(mid, out, sharpness=0.25, flags=fsr.FLAG_MATH_EXACT)
+    assert_exact32(host(mid), g["easu_f"], "B.2 easu")
+    assert_exact32(host(out), g["rcas_f"], "B.2 rcas")
+    assert abs(host(out).astype(np.float64).sum() - 19292.897310251) < 1e-6
+
+
+# ------------------------------------------------------------------------------------------------
+# live oracle on larger / awkward shapes
+# ------------------------------------------------------------------------------------------------
+SHAPES = [
+    (480, 270, 960, 540),     # 2.0x
+    (369, 208, 480, 270),     # 1.3x true-ratio preset shape scaled down
+    (564, 317, 960, 540),     # 1.7x
+    (640, 360, 960, 540),     # 1.5x
+    (97, 61, 131, 83),        # ragged, not tile aligned
+    (5, 3, 17, 9),            # smaller than one tile, tiny input
+    (64, 16, 64, 16),         # ratio 1.0
+    (300, 200, 200, 133),     # mild minification (footprint larger than the tile)
+]
+
+
+@pytest.mark.parametrize("shape", SHAPES, ids=lambda s: "%dx%d_to_%dx%d" % s)
+def test_easu_vs_oracle(fsr, port, shape):
+    iw, ih, ow, oh = shape
+    img = frames.synthetic_frame(iw, ih, k=1, dtype=np.float16)
+    con = fsr.FsrEasuCon(iw, ih, iw, ih, ow, oh)
+    want = port.easu_f(img.astype(np.float32), ow, oh, con)
+    out = torch.zeros(oh, ow, 4, dtype=torch.float16, device="cuda")
+    fsr.easu(dev(img), out, con=con, flags=fsr.FLAG_MATH_EXACT)
+    assert_exact16(host(out), want, "easu EXACT")
+    out.zero_()
+    fsr.easu(dev(img), out, con=con)
+    assert_f_class(host(out), want, "easu F")
+
+
+@pytest.mark.parametrize("shape", [(960, 540), (131, 83), (64, 16), (65, 17), (3, 2), (1, 1)], ids=lambda s: "%dx%d" % s)
+def test_rcas_vs_oracle(fsr, port, shape):
+    w, h = shape
+    img = frames.synthetic_frame(w, h, k=2, dtype=np.float16)
+    for stops in (0.0, 0.25, 1.5):
+        con = fsr.FsrRcasCon(stops)
+        want = port.rcas_f(img.astype(np.float32), con)
+        out = torch.zeros(h, w, 4, dtype=torch.float16, device="cuda")
+        fsr.rcas(dev(img), out, con=con, flags=fsr.FLAG_MATH_EXACT)
+        assert_exact16(host(out), want, "rcas EXACT %g" % stops)
+        out.zero_()
+        fsr.rcas(dev(img), out, con=con)
+        assert_f_class(host(out), want, "rcas F %g" % stops)
+
+
+def test_rcas_black_white_primaries(fsr, port):
+    """0*inf NaNs inside RCAS must be dropped by max(); exact 0.0 / 1.0 regions."""
+    img = np.zeros((40, 72, 4), np.float16)
+    img[..., 3] = 1
+    img[:, 8:16, :3] = 1.0
+    img[:, 16:24, 0] = 1.0
+    img[:, 24:32, 1] = 1.0
+    img[:, 32:40, 2] = 1.0
+    img[::2, 40:48, :3] = 1.0
+    img[:, 48:56, 1] = 0.5
+    img[17, 52, 1] = 0.8
+    con = fsr.FsrRcasCon(0.0)
+    want = port.rcas_f(img.astype(np.float32), con)
+    assert not np.isnan(want).any()
+    out = torch.zeros(40, 72, 4, dtype=torch.float16, device="cuda")
+    for fl in (fsr.FLAG_MATH_EXACT, 0):
+        out.fill_(7)
+        fsr.rcas(dev(img), out, con=con, flags=fl)
+        got = host(out)
+        assert not np.isnan(got.astype(np.float32)).any()
+        if fl:
+            assert_exact16(got, want, "rcas specials EXACT")
+        else:
+            assert_f_class(got, want, "rcas specials F")
+
+
+def test_easu_dynamic_resolution(fsr, port):
+    """FsrEasuConOffset: viewport (40x30 at offset 8,6) inside a 64x48 resource; taps clamp at the resource edge."""
+    img = frames.synthetic_frame(64, 48, k=2, dtype=np.float16)
+    con = fsr.FsrEasuConOffset(40, 30, 64, 48, 80, 60, 8, 6)
+    want = port.easu_f(img.astype(np.float32), 80, 60, con)
+    out = torch.zeros(60, 80, 4, dtype=torch.float16, device="cuda")
+    fsr.easu(dev(img), out, con=con, flags=fsr.FLAG_MATH_EXACT)
+    assert_exact16(host(out), want, "easu offset EXACT")
+
+
+def test_batch_and_strides(fsr, port):
+    """Frames of one launch are independent; row pitch and frame stride are honoured."""
+    iw, ih, ow, oh, n = 96, 54, 192, 108, 5
+    batch = np.stack([frames.synthetic_frame(iw, ih, k=k, dtype=np.float16) for k in range(n)])
+    con = fsr.FsrEasuCon(iw, ih, iw, ih, ow, oh)
+    padded_in = torch.zeros(n, ih + 3, iw + 5, 4, dtype=torch.float16, device="cuda")
+    padded_in[:, :ih, :iw] = dev(batch)
+    padded_out = torch.full((n, oh + 2, ow + 7, 4), 9.0, dtype=torch.float16, device="cuda")
+    fsr.easu(padded_in[:, :ih, :iw], padded_out[:, :oh, :ow], con=con, flags=fsr.FLAG_MATH_EXACT)
+    got = host(padded_out)
+    for k in range(n):
+        want = port.easu_f(batch[k].astype(np.float32), ow, oh, con)
+        assert_exact16(got[k, :oh, :ow], want, "frame %d" % k)
+    assert np.all(got[:, oh:, :, :] == 9.0) and np.all(got[:, :, ow:, :] == 9.0), "wrote outside the output view"
+    # RCAS on the same padded layout
+    sharp = torch.full_like(padded_out, 5.0)
+    rc = fsr.FsrRcasCon(0.25)
+    fsr.rcas(padded_out[:, :oh, :ow], sharp[:, :oh, :ow], con=rc, flags=fsr.FLAG_MATH_EXACT)
+    got2 = host(sharp)
+    for k in range(n):
+        want = port.rcas_f(got[k, :oh, :ow].astype(np.float32), rc)
+        assert_exact16(got2[k, :oh, :ow], want, "rcas frame %d" % k)
+    assert np.all(got2[:, oh:, :, :] == 5.0) and np.all(got2[:, :, ow:, :] == 5.0)
+
+
+def test_upscale_and_filter_mirror(fsr, port):
+    """fsr1_upscale / FSR_Filter.Upscale == FsrEasuCon + EASU + FsrRcasCon + RCAS (FSR_Filter.cpp:101-141)."""
+    iw, ih, ow, oh = 160, 90, 320, 180
+    img = frames.synthetic_frame(iw, ih, k=4, dtype=np.float16)
+    src = dev(img)
+    dst = torch.zeros(oh, ow, 4, dtype=torch.float16, device="cuda")
+    filt = fsr.FSR_Filter()
+    filt.OnCreate(slowFallback=True, exact=True)
+    filt.OnCreateWindowSizeDependentResources(src, dst, ow, oh, hdr=False)
+    state = fsr.State(iw, ih, bUseRcas=True, rcasAttenuation=0.25)
+    filt.Upscale(ow, oh, state)
+    con = port.FsrEasuCon(iw, ih, iw, ih, ow, oh)
+    mid = port.easu_f(img.astype(np.float32), ow, oh, con).astype(np.float16).astype(np.float32)
+    want = port.rcas_f(mid, port.FsrRcasCon(0.25))
+    assert_exact16(host(dst), want, "Upscale easu+rcas")
+    assert_exact16(host(filt.m_intermediary), mid, "intermediary")
+    # EASU only, hdr -> Sample.x = 1 on EASU (FSR_Filter.cpp:107)
+    state.bUseRcas = False
+    filt.Upscale(ow, oh, state, hdr=True)
+    want = port.easu_f(img.astype(np.float32), ow, oh, con, 4)
+    assert_exact16(host(dst), want, "Upscale easu-only hdr")
+    # hdr with RCAS: square applied after RCAS only (:125)
+    state.bUseRcas = True
+    filt.Upscale(ow, oh, state, hdr=True)
+    want = port.rcas_f(mid, port.FsrRcasCon(0.25), 4)
+    assert_exact16(host(dst), want, "Upscale easu+rcas hdr")
+    filt.OnDestroy()
+
+
+# ------------------------------------------------------------------------------------------------
+# BASELINE.json full sizes: oracle on row bands + size-independent properties
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape", [(1920, 1080, 3840, 2160), (2560, 1440, 3840, 2160)], ids=["1080p_to_4k", "1440p_to_4k"])
+def test_full_size_bands_and_properties(fsr, port, shape):
+    iw, ih, ow, oh = shape
+    img = frames.synthetic_frame(iw, ih, k=0, dtype=np.float16)
+    src = dev(img)
+    con = fsr.FsrEasuCon(iw, ih, iw, ih, ow, oh)
+    rc = fsr.FsrRcasCon(0.25)
+    mid = torch.zeros(oh, ow, 4, dtype=torch.float16, device="cuda")
+    out = torch.zeros_like(mid)
+    fsr.easu(src, mid, con=con)
+    fsr.rcas(mid, out, con=rc)
+    got_mid, got_out = host(mid), host(out)
+    img32 = img.astype(np.float32)
+    mid32 = got_mid.astype(np.float32)
+    for y0 in (0, oh // 2 - 8, oh - 16):  # top edge, middle, bottom edge
+        rows = (y0, y0 + 16)
+        want = port.easu_f(img32, ow, oh, con, 0, rows)[y0:y0 + 16]
+        assert_f_class(got_mid[y0:y0 + 16], want, "easu rows %d" % y0)
+        want = port.rcas_f(mid32, rc, 0, rows)[y0:y0 + 16]   # RCAS judged on identical input (the GPU's own EASU output)
+        assert_f_class(got_out[y0:y0 + 16], want, "rcas rows %d" % y0)
+    # properties: output alpha is 1, values stay inside the input's range per channel (EASU derings to the
+    # 2x2 neighbourhood: ffx_fsr1.h:437), a second run is bit-identical (determinism)
+    assert np.all(got_mid[..., 3] == 1.0) and np.all(got_out[..., 3] == 1.0)
+    for c in range(3):
+        assert got_mid[..., c].min() >= img[..., c].min() and got_mid[..., c].max() <= img[..., c].max()
+    mid2 = torch.zeros_like(mid)
+    fsr.easu(src, mid2, con=con)
+    assert torch.equal(mid, mid2)
+
+
+def test_constant_image_is_a_fixed_point(fsr):
+    """EASU of a constant image returns it (weights normalise, dering clamp = identity); RCAS of a constant
+    interior returns it: (lobe*4c + c) * rcp(4*lobe+1) within the medium-precision rcp (1 ULP of binary16)."""
+    for val in (0.0, 0.25, 0.7, 1.0):
+        src = torch.full((45, 80, 4), val, dtype=torch.float16, device="cuda")
+        src[..., 3] = 1
+        mid = torch.zeros(90, 160, 4, dtype=torch.float16, device="cuda")
+        fsr.easu(src, mid)
+        assert torch.equal(mid[..., :3], torch.full_like(mid[..., :3], val))
+        out = torch.zeros_like(mid)
+        fsr.rcas(mid, out)
+        inner = host(out)[1:-1, 1:-1, :3].astype(np.float32)
+        assert np.abs(inner - np.float32(np.float16(val))).max() <= 2 ** -10

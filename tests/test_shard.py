@@ -1,0 +1,51 @@
+"""Frame sharding across ranks (the only multi-GPU logic of the path) — pure index arithmetic plus a
+world_size-2 gloo run of the counter reduction bench.py performs."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+
+def test_frames_for_rank_partitions(fsr):
+    for total in (0, 1, 7, 8, 64, 128, 129):
+        for world in (1, 2, 3, 4, 8):
+            blocks = [fsr.frames_for_rank(total, r, world) for r in range(world)]
+            assert blocks[0][0] == 0 and blocks[-1][1] == total
+            assert all(blocks[i][1] == blocks[i + 1][0] for i in range(world - 1))
+            sizes = [e - b for b, e in blocks]
+            assert max(sizes) - min(sizes) <= 1
+    assert fsr.frames_for_rank(64, 3, 8) == (24, 32)   # BASELINE config 3: 8 frames per GPU
+    assert fsr.frames_for_rank(128, 7, 8) == (112, 128)  # config 5: 16 per GPU
+    with pytest.raises(ValueError):
+        fsr.frames_for_rank(8, 8, 8)
+
+
+WORKER = r"""
+import os, sys, importlib
+sys.path.insert(0, %(root)r)
+import torch, torch.distributed as dist
+fsr = importlib.import_module("fidelityfx-fsr_amd")
+import bench
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+b, e = fsr.frames_for_rank(13, rank, world)
+# each rank "processed" its frames in a rank-dependent time; the job time is the max over ranks
+res = bench.reduce_counters(frames=e - b, pixels=(e - b) * 100, seconds=0.5 + rank, device=torch.device("cpu"))
+assert res["frames"] == 13 and res["pixels"] == 1300 and abs(res["seconds"] - (0.5 + world - 1)) < 1e-9, res
+print("rank", rank, "ok", res)
+dist.destroy_process_group()
+"""
+
+
+def test_counter_reduction_gloo_world2(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER % {"root": ROOT})
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29631", str(script)],
+                         cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert out.stdout.count("ok") == 2
