@@ -80,6 +80,13 @@ def load():
             raise RuntimeError(
                 "%s not found: the HIP extension is not built (run `python -c 'import __graft_entry__ as g; g.build()'` "
                 "or `make -C fidelityfx-fsr_amd/csrc`). There is no CPU fallback." % LIB_PATH)
+        # One HIP runtime per process: torch wheels bundle their own libamdhip64 (same SONAME as the
+        # system one this library is linked to).  If torch is going to be used it must be loaded first so
+        # that this library binds to the runtime torch's allocator and streams live in.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         lib = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported

@@ -290,7 +290,8 @@ def test_full_size_bands_and_properties(fsr, port, shape):
 
 def test_constant_image_is_a_fixed_point(fsr):
     """EASU of a constant image returns it (weights normalise, dering clamp = identity); RCAS of a constant
-    interior returns it: (lobe*4c + c) * rcp(4*lobe+1) within the medium-precision rcp (1 ULP of binary16)."""
+    interior returns (lobe*4c + c) * APrxMedRcpF1(4*lobe+1) = c up to the error of the medium-precision
+    reciprocal (one Newton step from the integer estimate, ffx_a.h:1844: below 0.5 % relative)."""
     for val in (0.0, 0.25, 0.7, 1.0):
         src = torch.full((45, 80, 4), val, dtype=torch.float16, device="cuda")
         src[..., 3] = 1
@@ -300,4 +301,4 @@ def test_constant_image_is_a_fixed_point(fsr):
         out = torch.zeros_like(mid)
         fsr.rcas(mid, out)
         inner = host(out)[1:-1, 1:-1, :3].astype(np.float32)
-        assert np.abs(inner - np.float32(np.float16(val))).max() <= 2 ** -10
+        assert np.abs(inner - np.float32(np.float16(val))).max() <= 0.005 * val + 1e-7
