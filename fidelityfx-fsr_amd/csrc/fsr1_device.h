@@ -86,6 +86,12 @@ __device__ __forceinline__ int xcd_swizzle(int b, int n) {
   return xcd * q + (xcd < r ? xcd : r) + idx;
 }
 
+// Optimisation barrier for a value that is about to be narrowed.  LLVM folds fptrunc(fmul) / fptrunc(fma)
+// into v_fma_mixlo_f16 even with -ffp-contract=off, i.e. ONE rounding of the exact product to binary16
+// instead of the reference's binary32 product followed by the store's rounding.  The EXACT variants pin
+// the binary32 value first (costs no instruction).
+__device__ __forceinline__ float pinned(float x) { asm volatile("" : "+v"(x)); return x; }
+
 // RTNE float -> binary16 (v_cvt_f16_f32 under the default rounding mode; never cvt_pkrtz).
 __device__ __forceinline__ half_t to_half(float f) { return (half_t)f; }
 

@@ -51,6 +51,7 @@ __device__ __forceinline__ void rcas_pixel(float4_t b, float4_t d, float4_t e, f
     pb = fmaf(lobe, (b.z + d.z) + (h.z + f.z), e.z) * rcpL;
   }
   if (flags & FSR1_FLAG_HDR_SQUARE) { pr *= pr; pg *= pg; pb *= pb; }  // FSR_Pass.hlsl:92-93
+  if (EXACT) { pr = pinned(pr); pg = pinned(pg); pb = pinned(pb); }
 }
 
 template <int FMT, bool EXACT>
