@@ -13,6 +13,7 @@ namespace fsr1 {
 hipError_t easu_launch(const EasuArgs& a, int fmt, bool exact, hipStream_t stream);
 size_t easu_lds_bytes(int fmt, int fp_w, int fp_h);
 hipError_t rcas_launch(const RcasArgs& a, int fmt, bool exact, hipStream_t stream);
+void rcas_geometry(int width, int height, int* tiles_x, int* tiles_y);
 hipError_t fused_launch(const FusedArgs& a, int fmt, bool exact, hipStream_t stream);
 size_t fused_lds_bytes(int fmt, int fp_w, int fp_h);
 hipError_t easu_h_launch(const EasuArgs& a, hipStream_t stream);
@@ -148,8 +149,7 @@ int fsr1_rcas_dispatch(const fsr1_image* in, const fsr1_image* out, const uint32
                 in->frames, out->width, out->height, out->frames);
   if (overlaps(in, a.in, out, a.out)) return fail(FSR1_ERR_INVALID_ARGUMENT, "rcas: input and output overlap (RCAS cannot run in place)");
   memcpy(a.con, con, sizeof a.con);
-  a.tiles_x = (out->width + kTileW - 1) / kTileW;
-  a.tiles_y = (out->height + kTileH - 1) / kTileH;
+  rcas_geometry(out->width, out->height, &a.tiles_x, &a.tiles_y);
   a.frames = out->frames;
   a.flags = flags;
   hipError_t e;

@@ -1,39 +1,67 @@
 // RCAS — robust contrast adaptive sharpening (FsrRcasF, ffx-fsr/ffx_fsr1.h:684-769) for gfx950.
 //
-// HBM-bound pass: 8 B read + 8 B written per pixel (RGBA16F).  A 256-thread workgroup stages the
-// (64+2)x(16+2) input window of its 64x16 output tile in LDS (texels outside the image are 0, the
-// D3D `Load` rule of the reference's callback, FSR_Pass.hlsl:45,61), then each lane sharpens the 4
-// pixels of its column and every wave issues row-contiguous stores.
+// 8 B read + 8 B written per pixel (RGBA16F) against ~100 VALU instructions: on MI355X the pass sits
+// right at the HBM/VALU balance point, so the kernel is built to touch every input byte once and to
+// spend no instruction on staging:
+//   * no LDS, no barrier: a wave owns a 64-column x 24-row strip and streams down it; the vertical
+//     neighbours (b above, h below) are the lane's own previous/next rows kept in registers, the
+//     horizontal neighbours (d left, f right) are the adjacent lanes' centre texels fetched with DPP
+//     wave shifts (v_mov_b32_dpp wave_shr:1 / wave_shl:1);
+//   * lanes 0 and 63 additionally load the one texel left / right of the strip, which the DPP move
+//     leaves in place for exactly those lanes (an invalid DPP source keeps the old destination);
+//   * every texel is converted to fp32 once; loads run 3 rows ahead of the arithmetic;
+//   * texels outside the image are 0 (the D3D `Load` rule of the reference's callback, FSR_Pass.hlsl:45,61).
 #include "fsr1_device.h"
 
 namespace fsr1 {
 
-constexpr int kRcasW = kTileW + 2;
-constexpr int kRcasH = kTileH + 2;
+constexpr int kRcasRows = 24;             // rows per strip: 1080, 2160 and 4320 are multiples
+constexpr int kRcasCols = 64 * 4;         // columns per 256-thread workgroup (4 waves side by side)
+constexpr int kDppWaveShr1 = 0x138;       // lane i <- lane i-1
+constexpr int kDppWaveShl1 = 0x130;       // lane i <- lane i+1
+
+// raw texel of the lane to the left / right; `keep` stays where the neighbour lane does not exist
+template <int CTRL>
+__device__ __forceinline__ half4_t neighbour(const half4_t& keep, const half4_t& v) {
+  const uint2 c = __builtin_bit_cast(uint2, v), k = __builtin_bit_cast(uint2, keep);
+  const uint2 r = {(uint32_t)__builtin_amdgcn_update_dpp((int)k.x, (int)c.x, CTRL, 0xf, 0xf, false),
+                   (uint32_t)__builtin_amdgcn_update_dpp((int)k.y, (int)c.y, CTRL, 0xf, 0xf, false)};
+  return __builtin_bit_cast(half4_t, r);
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float keep, float v) {  // by value: bit_cast of a vector-element lvalue reads element 0
+  return as_f32((uint32_t)__builtin_amdgcn_update_dpp((int)as_u32(keep), (int)as_u32(v), CTRL, 0xf, 0xf, false));
+}
+template <int CTRL>
+__device__ __forceinline__ float4_t neighbour(const float4_t& keep, const float4_t& v) {
+  const float kx = keep.x, ky = keep.y, kz = keep.z, vx = v.x, vy = v.y, vz = v.z;
+  return float4_t{dpp_f32<CTRL>(kx, vx), dpp_f32<CTRL>(ky, vy), dpp_f32<CTRL>(kz, vz), 0.0f};
+}
+
+struct rgb_t { float r, g, b; };
 
 // One pixel of FsrRcasF from its 5 taps (b above, d left, e centre, f right, h below).
 template <bool EXACT>
-__device__ __forceinline__ void rcas_pixel(float4_t b, float4_t d, float4_t e, float4_t f, float4_t h, float sharp,
-                                           uint32_t flags, float& pr, float& pg, float& pb) {
+__device__ __forceinline__ rgb_t rcas_pixel(rgb_t b, rgb_t d, rgb_t e, rgb_t f, rgb_t h, float sharp, uint32_t flags) {  // flags: compile-time 0 in the plain variant
   // :741-746 min and max of the ring, per channel
-  const float mn4R = fminf(min3f(b.x, d.x, f.x), h.x), mn4G = fminf(min3f(b.y, d.y, f.y), h.y), mn4B = fminf(min3f(b.z, d.z, f.z), h.z);
-  const float mx4R = fmaxf(max3f(b.x, d.x, f.x), h.x), mx4G = fmaxf(max3f(b.y, d.y, f.y), h.y), mx4B = fmaxf(max3f(b.z, d.z, f.z), h.z);
+  const float mn4R = fminf(min3f(b.r, d.r, f.r), h.r), mn4G = fminf(min3f(b.g, d.g, f.g), h.g), mn4B = fminf(min3f(b.b, d.b, f.b), h.b);
+  const float mx4R = fmaxf(max3f(b.r, d.r, f.r), h.r), mx4G = fmaxf(max3f(b.g, d.g, f.g), h.g), mx4B = fmaxf(max3f(b.b, d.b, f.b), h.b);
   // :748-755 limiters; "these need to be high precision RCPs": IEEE division when EXACT, v_rcp_f32 (1 ulp) otherwise.
   // 4*x and 4*x-4 are exact scalings, so fusing the latter does not change it (barring overflow).
   auto rcp = [](float x) { return EXACT ? 1.0f / x : __builtin_amdgcn_rcpf(x); };
-  const float hitMinR = fminf(mn4R, e.x) * rcp(4.0f * mx4R);
-  const float hitMinG = fminf(mn4G, e.y) * rcp(4.0f * mx4G);
-  const float hitMinB = fminf(mn4B, e.z) * rcp(4.0f * mx4B);
-  const float hitMaxR = (1.0f - fmaxf(mx4R, e.x)) * rcp(4.0f * mn4R + -4.0f);
-  const float hitMaxG = (1.0f - fmaxf(mx4G, e.y)) * rcp(4.0f * mn4G + -4.0f);
-  const float hitMaxB = (1.0f - fmaxf(mx4B, e.z)) * rcp(4.0f * mn4B + -4.0f);
+  const float hitMinR = fminf(mn4R, e.r) * rcp(4.0f * mx4R);
+  const float hitMinG = fminf(mn4G, e.g) * rcp(4.0f * mx4G);
+  const float hitMinB = fminf(mn4B, e.b) * rcp(4.0f * mx4B);
+  const float hitMaxR = (1.0f - fmaxf(mx4R, e.r)) * rcp(fmaf(4.0f, mn4R, -4.0f));
+  const float hitMaxG = (1.0f - fmaxf(mx4G, e.g)) * rcp(fmaf(4.0f, mn4G, -4.0f));
+  const float hitMaxB = (1.0f - fmaxf(mx4B, e.b)) * rcp(fmaf(4.0f, mn4B, -4.0f));
   // :756-759  max() must return the non-NaN operand (0*inf on black pixels): v_max_f32 does.
   const float lobeR = fmaxf(-hitMinR, hitMaxR), lobeG = fmaxf(-hitMinG, hitMaxG), lobeB = fmaxf(-hitMinB, hitMaxB);
   float lobe = fmaxf(-(0.25f - (1.0f / 16.0f)), fminf(max3f(lobeR, lobeG, lobeB), 0.0f)) * sharp;
   if (flags & FSR1_FLAG_RCAS_DENOISE) {  // :731-739, :761-763
-    const float bL = fmaf(b.z, 0.5f, fmaf(b.x, 0.5f, b.y)), dL = fmaf(d.z, 0.5f, fmaf(d.x, 0.5f, d.y));
-    const float eL = fmaf(e.z, 0.5f, fmaf(e.x, 0.5f, e.y)), fL = fmaf(f.z, 0.5f, fmaf(f.x, 0.5f, f.y));
-    const float hL = fmaf(h.z, 0.5f, fmaf(h.x, 0.5f, h.y));
+    const float bL = fmaf(b.b, 0.5f, fmaf(b.r, 0.5f, b.g)), dL = fmaf(d.b, 0.5f, fmaf(d.r, 0.5f, d.g));
+    const float eL = fmaf(e.b, 0.5f, fmaf(e.r, 0.5f, e.g)), fL = fmaf(f.b, 0.5f, fmaf(f.r, 0.5f, f.g));
+    const float hL = fmaf(h.b, 0.5f, fmaf(h.r, 0.5f, h.g));
     float nz = 0.25f * bL + 0.25f * dL + 0.25f * fL + 0.25f * hL - eL;
     nz = sat(fabsf(nz) * APrxMedRcpF1<EXACT>(max3f(max3f(bL, dL, eL), fL, hL) - min3f(min3f(bL, dL, eL), fL, hL)));
     nz = mad<EXACT>(-0.5f, nz, 1.0f);
@@ -41,77 +69,106 @@ __device__ __forceinline__ void rcas_pixel(float4_t b, float4_t d, float4_t e, f
   }
   // :765-768 resolve
   const float rcpL = APrxMedRcpF1<EXACT>(mad<EXACT>(4.0f, lobe, 1.0f));
+  rgb_t p;
   if (EXACT) {
-    pr = (lobe * b.x + lobe * d.x + lobe * h.x + lobe * f.x + e.x) * rcpL;
-    pg = (lobe * b.y + lobe * d.y + lobe * h.y + lobe * f.y + e.y) * rcpL;
-    pb = (lobe * b.z + lobe * d.z + lobe * h.z + lobe * f.z + e.z) * rcpL;
+    p.r = (lobe * b.r + lobe * d.r + lobe * h.r + lobe * f.r + e.r) * rcpL;
+    p.g = (lobe * b.g + lobe * d.g + lobe * h.g + lobe * f.g + e.g) * rcpL;
+    p.b = (lobe * b.b + lobe * d.b + lobe * h.b + lobe * f.b + e.b) * rcpL;
   } else {
-    pr = fmaf(lobe, (b.x + d.x) + (h.x + f.x), e.x) * rcpL;
-    pg = fmaf(lobe, (b.y + d.y) + (h.y + f.y), e.y) * rcpL;
-    pb = fmaf(lobe, (b.z + d.z) + (h.z + f.z), e.z) * rcpL;
+    p.r = fmaf(lobe, (b.r + h.r) + (d.r + f.r), e.r) * rcpL;
+    p.g = fmaf(lobe, (b.g + h.g) + (d.g + f.g), e.g) * rcpL;
+    p.b = fmaf(lobe, (b.b + h.b) + (d.b + f.b), e.b) * rcpL;
   }
-  if (flags & FSR1_FLAG_HDR_SQUARE) { pr *= pr; pg *= pg; pb *= pb; }  // FSR_Pass.hlsl:92-93
-  if (EXACT) { pr = pinned(pr); pg = pinned(pg); pb = pinned(pb); }
+  if (flags & FSR1_FLAG_HDR_SQUARE) { p.r *= p.r; p.g *= p.g; p.b *= p.b; }  // FSR_Pass.hlsl:92-93
+  if (EXACT) { p.r = pinned(p.r); p.g = pinned(p.g); p.b = pinned(p.b); }
+  return p;
 }
 
-template <int FMT, bool EXACT>
+// OPTS = false: the plain pass (no denoise / alpha pass-through / HDR square), flags compiled out.
+template <int FMT, bool EXACT, bool OPTS>
 __global__ void __launch_bounds__(kThreads) rcas_kernel(const RcasArgs a) {
   typedef typename Pixel<FMT>::T texel_t;
-  __shared__ texel_t tile[kRcasH][kRcasW];
-
+  const uint32_t flags = OPTS ? a.flags : 0u;
   const int tiles_per_frame = a.tiles_x * a.tiles_y;
   const int t = xcd_swizzle(blockIdx.x, tiles_per_frame * a.frames);
   const int frame = t / tiles_per_frame;
   const int tf = t - frame * tiles_per_frame;
   const int ty = tf / a.tiles_x, tx = tf - ty * a.tiles_x;
-  const int ox0 = tx * kTileW, oy0 = ty * kTileH;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const char* const in_frame = a.in.base + (long long)frame * a.in.frame_stride;
+  const int x0 = tx * kRcasCols + wave * 64, y0 = ty * kRcasRows;
+  if (x0 >= a.in.width) return;  // whole wave outside (no barriers in this kernel)
 
-  for (int ly = wave; ly < kRcasH; ly += 4) {
-    const int gy = oy0 - 1 + ly;
-    const bool rowok = gy >= 0 && gy < a.in.height;
-    const char* const row = in_frame + (long long)gy * a.in.pitch;
-    for (int lx = lane; lx < kRcasW; lx += 64) {
-      const int gx = ox0 - 1 + lx;
-      texel_t px = Pixel<FMT>::zero();
-      if (rowok && gx >= 0 && gx < a.in.width) px = *reinterpret_cast<const texel_t*>(row + (size_t)gx * sizeof(texel_t));
-      tile[ly][lx] = px;
+  const int W = a.in.width, H = a.in.height;
+  const int col = x0 + lane;
+  const bool col_ok = col < W;
+  // the strip's left / right apron column, owned by lanes 0 / 63
+  const int hcol = lane == 0 ? x0 - 1 : x0 + 64;
+  const bool halo_ok = (lane == 0 || lane == 63) && hcol >= 0 && hcol < W;
+  const char* const in_col = a.in.base + (long long)frame * a.in.frame_stride + (size_t)col * sizeof(texel_t);
+  const char* const in_hcol = a.in.base + (long long)frame * a.in.frame_stride + (size_t)hcol * sizeof(texel_t);
+  char* const out_col = a.out.base + (long long)frame * a.out.frame_stride + (size_t)col * sizeof(texel_t);
+
+  auto load = [&](int y, texel_t& own, texel_t& halo) {
+    own = Pixel<FMT>::zero();
+    halo = Pixel<FMT>::zero();
+    if (y >= 0 && y < H) {  // wave-uniform
+      if (col_ok) own = *reinterpret_cast<const texel_t*>(in_col + (long long)y * a.in.pitch);
+      if (halo_ok) halo = *reinterpret_cast<const texel_t*>(in_hcol + (long long)y * a.in.pitch);
     }
-  }
-  __syncthreads();
+  };
+  auto rgb = [](const texel_t& p) { const float4_t c = Pixel<FMT>::load(p); return rgb_t{c.x, c.y, c.z}; };
+  // Loop-carried fp32 values reach v_min/v_max through a block boundary, where the compiler no longer
+  // knows they are canonical and would spend a v_max_f32 x,x,x (4.3 cycles) on each; x+0.0 (2.4 cycles)
+  // tells it the same thing.  It turns -0 into +0, so the EXACT variant does not use it.
+  auto known = [](rgb_t v) { return EXACT ? v : rgb_t{v.r + 0.0f, v.g + 0.0f, v.b + 0.0f}; };
 
-  const int ox = ox0 + lane;
-  if (ox >= a.out.width) return;
-  const float sharp = as_f32(a.con[0]);
-  char* const out_frame = a.out.base + (long long)frame * a.out.frame_stride;
+  // Ring of raw rows: slot (r+k) % kRing holds row y0+r+k, k = 0..kAhead; with the row loop fully
+  // unrolled every index is static, so the ring lives in registers and loads run kAhead rows ahead.
+  constexpr int kAhead = FMT == FSR1_FORMAT_RGBA16F ? 6 : 3, kRing = kAhead + 1;
+  texel_t q[kRing], g[kRing];
+  rgb_t prev, cur;
+  {
+    texel_t q_prev, g_prev;
+    load(y0 - 1, q_prev, g_prev);
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int ry = wave * 4 + r;
-    const int oy = oy0 + ry;
-    if (oy >= a.out.height) break;
-    const float4_t b = Pixel<FMT>::load(tile[ry][lane + 1]);
-    const float4_t d = Pixel<FMT>::load(tile[ry + 1][lane]);
-    const float4_t e = Pixel<FMT>::load(tile[ry + 1][lane + 1]);
-    const float4_t f = Pixel<FMT>::load(tile[ry + 1][lane + 2]);
-    const float4_t h = Pixel<FMT>::load(tile[ry + 2][lane + 1]);
-    float pr, pg, pb;
-    rcas_pixel<EXACT>(b, d, e, f, h, sharp, a.flags, pr, pg, pb);
-    const float pa = (a.flags & FSR1_FLAG_RCAS_PASSTHROUGH_ALPHA) ? e.w : 1.0f;  // :700-705 / FSR_Pass.hlsl:94
-    *reinterpret_cast<texel_t*>(out_frame + (long long)oy * a.out.pitch + (size_t)ox * sizeof(texel_t)) =
-        Pixel<FMT>::store(pr, pg, pb, pa);
+    for (int k = 0; k < kAhead; ++k) load(y0 + k, q[k], g[k]);
+    prev = rgb(q_prev);
+    cur = rgb(q[0]);
   }
+  const float sharp = as_f32(a.con[0]);
+
+#pragma unroll
+  for (int r = 0; r < kRcasRows; ++r) {
+    const int y = y0 + r;
+    load(y + kAhead, q[(r + kAhead) % kRing], g[(r + kAhead) % kRing]);
+    const texel_t& q_cur = q[r % kRing];
+    const texel_t& g_cur = g[r % kRing];
+    const rgb_t next = rgb(q[(r + 1) % kRing]);
+    // horizontal neighbours: the adjacent lanes' raw centre texel; lanes 0 / 63 keep their apron texel
+    const texel_t dq = neighbour<kDppWaveShr1>(g_cur, q_cur), fq = neighbour<kDppWaveShl1>(g_cur, q_cur);
+    const rgb_t p = rcas_pixel<EXACT>(known(prev), rgb(dq), known(cur), rgb(fq), next, sharp, flags);
+    if (col_ok && y < H) {
+      const float pa = (flags & FSR1_FLAG_RCAS_PASSTHROUGH_ALPHA) ? Pixel<FMT>::load(q_cur).w : 1.0f;  // :700-705 / FSR_Pass.hlsl:94
+      *reinterpret_cast<texel_t*>(out_col + (long long)y * a.out.pitch) = Pixel<FMT>::store(p.r, p.g, p.b, pa);
+    }
+    prev = cur; cur = next;
+  }
+}
+
+void rcas_geometry(int width, int height, int* tiles_x, int* tiles_y) {
+  *tiles_x = (width + kRcasCols - 1) / kRcasCols;
+  *tiles_y = (height + kRcasRows - 1) / kRcasRows;
 }
 
 hipError_t rcas_launch(const RcasArgs& a, int fmt, bool exact, hipStream_t stream) {
   const dim3 grid((unsigned)(a.tiles_x * a.tiles_y * a.frames)), block(kThreads);
-  if (fmt == FSR1_FORMAT_RGBA16F) {
-    if (exact) hipLaunchKernelGGL((rcas_kernel<FSR1_FORMAT_RGBA16F, true>), grid, block, 0, stream, a);
-    else hipLaunchKernelGGL((rcas_kernel<FSR1_FORMAT_RGBA16F, false>), grid, block, 0, stream, a);
-  } else {
-    if (exact) hipLaunchKernelGGL((rcas_kernel<FSR1_FORMAT_RGBA32F, true>), grid, block, 0, stream, a);
-    else hipLaunchKernelGGL((rcas_kernel<FSR1_FORMAT_RGBA32F, false>), grid, block, 0, stream, a);
-  }
+  const bool opts = (a.flags & (FSR1_FLAG_RCAS_DENOISE | FSR1_FLAG_RCAS_PASSTHROUGH_ALPHA | FSR1_FLAG_HDR_SQUARE)) != 0;
+#define FSR1_RCAS(F, E, O) hipLaunchKernelGGL((rcas_kernel<F, E, O>), grid, block, 0, stream, a)
+#define FSR1_RCAS_O(F, E) do { if (opts) FSR1_RCAS(F, E, true); else FSR1_RCAS(F, E, false); } while (0)
+  if (fmt == FSR1_FORMAT_RGBA16F) { if (exact) FSR1_RCAS_O(FSR1_FORMAT_RGBA16F, true); else FSR1_RCAS_O(FSR1_FORMAT_RGBA16F, false); }
+  else { if (exact) FSR1_RCAS_O(FSR1_FORMAT_RGBA32F, true); else FSR1_RCAS_O(FSR1_FORMAT_RGBA32F, false); }
+#undef FSR1_RCAS_O
+#undef FSR1_RCAS
   return hipGetLastError();
 }
 
