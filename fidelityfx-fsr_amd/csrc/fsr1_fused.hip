@@ -1,0 +1,114 @@
+// EASU -> RCAS in one launch (BASELINE config 4; no counterpart in the reference, which always runs two
+// dispatches with a UAV->SRV barrier in between: sample/src/DX12/FSR_Filter.cpp:121-131).
+//
+// A 256-thread workgroup owns a 64x16 tile of the final image:
+//   phases 1-2  input footprint of the tile *plus a 1-pixel apron* -> LDS (shared with the EASU kernel);
+//   phase 3     FsrEasuF for the (64+2)x(16+2) apron tile, rounded to the storage format exactly as the
+//               two-pass pipeline's intermediary would be, kept in LDS (pixels outside the image are 0:
+//               the `Load` rule RCAS sees in the two-pass pipeline, FSR_Pass.hlsl:45,61);
+//   phase 4     FsrRcasF from that LDS tile, one row-contiguous store per wave.
+// The result is bit-identical to fsr1_easu_dispatch + fsr1_rcas_dispatch with an intermediary of the
+// output's format; the 2 x out bytes of HBM traffic of the intermediary are gone, at the price of
+// recomputing EASU on the apron (+16 % pixels).
+#include "fsr1_device.h"
+#include "fsr1_easu_math.h"
+#include "fsr1_rcas_math.h"
+
+namespace fsr1 {
+
+constexpr int kMidW = kTileW + 2;
+constexpr int kMidH = kTileH + 2;
+
+template <int FMT, bool EXACT>
+__global__ void __launch_bounds__(kThreads) fused_kernel(const FusedArgs a) {
+  typedef typename Pixel<FMT>::T texel_t;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int cap = a.fp_w * a.fp_h;
+  EasuLds l = easu_lds_carve(smem, cap);
+  texel_t* const mid = reinterpret_cast<texel_t*>(smem + (size_t)cap * kEasuLdsPerTexel);  // [kMidH][kMidW]
+
+  const int tiles_per_frame = a.tiles_x * a.tiles_y;
+  const int t = xcd_swizzle(blockIdx.x, tiles_per_frame * a.frames);
+  const int frame = t / tiles_per_frame;
+  const int tf = t - frame * tiles_per_frame;
+  const int ty = tf / a.tiles_x, tx = tf - ty * a.tiles_x;
+  const int ox0 = tx * kTileW, oy0 = ty * kTileH;
+  const int W = a.out.width, H = a.out.height;
+
+  const float c0x = as_f32(a.easu_con[0]), c0y = as_f32(a.easu_con[1]), c0z = as_f32(a.easu_con[2]), c0w = as_f32(a.easu_con[3]);
+
+  // apron tile = output pixels [ox0-1, ox0+64] x [oy0-1, oy0+16], clipped to the image for the footprint
+  const int ax0 = max(ox0 - 1, 0), ay0 = max(oy0 - 1, 0);
+  const int axl = min(ox0 + kTileW, W - 1), ayl = min(oy0 + kTileH, H - 1);
+  const int fx0 = (int)floorf((float)ax0 * c0x + c0z) - 1;
+  const int fy0 = (int)floorf((float)ay0 * c0y + c0w) - 1;
+  const int fw = min((int)floorf((float)axl * c0x + c0z) + 2 - fx0 + 1, a.fp_w);
+  const int fh = min((int)floorf((float)ayl * c0y + c0w) + 2 - fy0 + 1, a.fp_h);
+  l.fw = fw;
+
+  const int tid = threadIdx.x;
+  easu_stage_footprint<FMT>(l, a.in, a.in.base + (long long)frame * a.in.frame_stride, fx0, fy0, fw, fh, tid);
+
+  // ---- phase 3: EASU on the apron tile -> LDS, in the storage format (EASU runs with Sample.x = 0 when
+  //      RCAS follows: FSR_Filter.cpp:107) ----
+  for (int i = tid; i < kMidW * kMidH; i += kThreads) {
+    const int my = i / kMidW, mx = i - my * kMidW;
+    const int ox = ox0 - 1 + mx, oy = oy0 - 1 + my;
+    texel_t px = Pixel<FMT>::zero();
+    if (ox >= 0 && ox < W && oy >= 0 && oy < H) {
+      float ppx = (float)ox * c0x + c0z, ppy = (float)oy * c0y + c0w;  // :324-326
+      const float fpx = floorf(ppx), fpy = floorf(ppy);
+      ppx -= fpx;
+      ppy -= fpy;
+      const int f_idx = ((int)fpy - fy0) * fw + ((int)fpx - fx0);
+      px = easu_resolve<FMT, EXACT>(l, f_idx, easu_pixel<EXACT>(l, f_idx, ppx, ppy), false);
+    }
+    mid[i] = px;
+  }
+  __syncthreads();
+
+  // ---- phase 4: RCAS from the LDS tile ----
+  const int lane = tid & 63, wave = tid >> 6;
+  const int ox = ox0 + lane;
+  if (ox >= W) return;
+  const float sharp = as_f32(a.rcas_con[0]);
+  const uint32_t flags = a.flags;
+  char* const out_col = a.out.base + (long long)frame * a.out.frame_stride + (size_t)ox * sizeof(texel_t);
+  auto rgb = [](const texel_t& p) { const float4_t c = Pixel<FMT>::load(p); return rgb_t{c.x, c.y, c.z}; };
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int ry = wave * 4 + r;
+    const int oy = oy0 + ry;
+    if (oy >= H) break;
+    const texel_t* const c = mid + (ry + 1) * kMidW + (lane + 1);
+    const texel_t e = c[0];
+    const rgb_t p = rcas_pixel<EXACT>(rgb(c[-kMidW]), rgb(c[-1]), rgb(e), rgb(c[1]), rgb(c[kMidW]), sharp, flags);
+    const float pa = (flags & FSR1_FLAG_RCAS_PASSTHROUGH_ALPHA) ? Pixel<FMT>::load(e).w : 1.0f;
+    *reinterpret_cast<texel_t*>(out_col + (long long)oy * a.out.pitch) = Pixel<FMT>::store(p.r, p.g, p.b, pa);
+  }
+}
+
+size_t fused_lds_bytes(int fmt, int fp_w, int fp_h) {
+  const size_t texel = fmt == FSR1_FORMAT_RGBA16F ? 8 : 16;
+  return (size_t)fp_w * fp_h * kEasuLdsPerTexel + (size_t)kMidW * kMidH * texel;
+}
+
+hipError_t fused_launch(const FusedArgs& a, int fmt, bool exact, hipStream_t stream) {
+  const dim3 grid((unsigned)(a.tiles_x * a.tiles_y * a.frames)), block(kThreads);
+  const size_t lds = fused_lds_bytes(fmt, a.fp_w, a.fp_h);
+#define FSR1_LAUNCH(F, E)                                                                               \
+  do {                                                                                                  \
+    if (lds > 48 * 1024) {                                                                              \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_kernel<F, E>),            \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);        \
+      if (e != hipSuccess) return e;                                                                    \
+    }                                                                                                   \
+    hipLaunchKernelGGL((fused_kernel<F, E>), grid, block, lds, stream, a);                              \
+  } while (0)
+  if (fmt == FSR1_FORMAT_RGBA16F) { if (exact) FSR1_LAUNCH(FSR1_FORMAT_RGBA16F, true); else FSR1_LAUNCH(FSR1_FORMAT_RGBA16F, false); }
+  else { if (exact) FSR1_LAUNCH(FSR1_FORMAT_RGBA32F, true); else FSR1_LAUNCH(FSR1_FORMAT_RGBA32F, false); }
+#undef FSR1_LAUNCH
+  return hipGetLastError();
+}
+
+}  // namespace fsr1

@@ -12,6 +12,7 @@
 //   * every texel is converted to fp32 once; loads run 3 rows ahead of the arithmetic;
 //   * texels outside the image are 0 (the D3D `Load` rule of the reference's callback, FSR_Pass.hlsl:45,61).
 #include "fsr1_device.h"
+#include "fsr1_rcas_math.h"
 
 namespace fsr1 {
 
@@ -36,52 +37,6 @@ template <int CTRL>
 __device__ __forceinline__ float4_t neighbour(const float4_t& keep, const float4_t& v) {
   const float kx = keep.x, ky = keep.y, kz = keep.z, vx = v.x, vy = v.y, vz = v.z;
   return float4_t{dpp_f32<CTRL>(kx, vx), dpp_f32<CTRL>(ky, vy), dpp_f32<CTRL>(kz, vz), 0.0f};
-}
-
-struct rgb_t { float r, g, b; };
-
-// One pixel of FsrRcasF from its 5 taps (b above, d left, e centre, f right, h below).
-template <bool EXACT>
-__device__ __forceinline__ rgb_t rcas_pixel(rgb_t b, rgb_t d, rgb_t e, rgb_t f, rgb_t h, float sharp, uint32_t flags) {  // flags: compile-time 0 in the plain variant
-  // :741-746 min and max of the ring, per channel
-  const float mn4R = fminf(min3f(b.r, d.r, f.r), h.r), mn4G = fminf(min3f(b.g, d.g, f.g), h.g), mn4B = fminf(min3f(b.b, d.b, f.b), h.b);
-  const float mx4R = fmaxf(max3f(b.r, d.r, f.r), h.r), mx4G = fmaxf(max3f(b.g, d.g, f.g), h.g), mx4B = fmaxf(max3f(b.b, d.b, f.b), h.b);
-  // :748-755 limiters; "these need to be high precision RCPs": IEEE division when EXACT, v_rcp_f32 (1 ulp) otherwise.
-  // 4*x and 4*x-4 are exact scalings, so fusing the latter does not change it (barring overflow).
-  auto rcp = [](float x) { return EXACT ? 1.0f / x : __builtin_amdgcn_rcpf(x); };
-  const float hitMinR = fminf(mn4R, e.r) * rcp(4.0f * mx4R);
-  const float hitMinG = fminf(mn4G, e.g) * rcp(4.0f * mx4G);
-  const float hitMinB = fminf(mn4B, e.b) * rcp(4.0f * mx4B);
-  const float hitMaxR = (1.0f - fmaxf(mx4R, e.r)) * rcp(fmaf(4.0f, mn4R, -4.0f));
-  const float hitMaxG = (1.0f - fmaxf(mx4G, e.g)) * rcp(fmaf(4.0f, mn4G, -4.0f));
-  const float hitMaxB = (1.0f - fmaxf(mx4B, e.b)) * rcp(fmaf(4.0f, mn4B, -4.0f));
-  // :756-759  max() must return the non-NaN operand (0*inf on black pixels): v_max_f32 does.
-  const float lobeR = fmaxf(-hitMinR, hitMaxR), lobeG = fmaxf(-hitMinG, hitMaxG), lobeB = fmaxf(-hitMinB, hitMaxB);
-  float lobe = fmaxf(-(0.25f - (1.0f / 16.0f)), fminf(max3f(lobeR, lobeG, lobeB), 0.0f)) * sharp;
-  if (flags & FSR1_FLAG_RCAS_DENOISE) {  // :731-739, :761-763
-    const float bL = fmaf(b.b, 0.5f, fmaf(b.r, 0.5f, b.g)), dL = fmaf(d.b, 0.5f, fmaf(d.r, 0.5f, d.g));
-    const float eL = fmaf(e.b, 0.5f, fmaf(e.r, 0.5f, e.g)), fL = fmaf(f.b, 0.5f, fmaf(f.r, 0.5f, f.g));
-    const float hL = fmaf(h.b, 0.5f, fmaf(h.r, 0.5f, h.g));
-    float nz = 0.25f * bL + 0.25f * dL + 0.25f * fL + 0.25f * hL - eL;
-    nz = sat(fabsf(nz) * APrxMedRcpF1<EXACT>(max3f(max3f(bL, dL, eL), fL, hL) - min3f(min3f(bL, dL, eL), fL, hL)));
-    nz = mad<EXACT>(-0.5f, nz, 1.0f);
-    lobe *= nz;
-  }
-  // :765-768 resolve
-  const float rcpL = APrxMedRcpF1<EXACT>(mad<EXACT>(4.0f, lobe, 1.0f));
-  rgb_t p;
-  if (EXACT) {
-    p.r = (lobe * b.r + lobe * d.r + lobe * h.r + lobe * f.r + e.r) * rcpL;
-    p.g = (lobe * b.g + lobe * d.g + lobe * h.g + lobe * f.g + e.g) * rcpL;
-    p.b = (lobe * b.b + lobe * d.b + lobe * h.b + lobe * f.b + e.b) * rcpL;
-  } else {
-    p.r = fmaf(lobe, (b.r + h.r) + (d.r + f.r), e.r) * rcpL;
-    p.g = fmaf(lobe, (b.g + h.g) + (d.g + f.g), e.g) * rcpL;
-    p.b = fmaf(lobe, (b.b + h.b) + (d.b + f.b), e.b) * rcpL;
-  }
-  if (flags & FSR1_FLAG_HDR_SQUARE) { p.r *= p.r; p.g *= p.g; p.b *= p.b; }  // FSR_Pass.hlsl:92-93
-  if (EXACT) { p.r = pinned(p.r); p.g = pinned(p.g); p.b = pinned(p.b); }
-  return p;
 }
 
 // OPTS = false: the plain pass (no denoise / alpha pass-through / HDR square), flags compiled out.

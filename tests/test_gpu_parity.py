@@ -255,6 +255,52 @@ def test_upscale_and_filter_mirror(fsr, port):
     filt.OnDestroy()
 
 
+@pytest.mark.parametrize("shape", [(480, 270, 960, 540), (97, 61, 131, 83), (640, 360, 960, 540), (5, 3, 17, 9), (64, 16, 64, 16)],
+                         ids=lambda s: "%dx%d_to_%dx%d" % s)
+def test_fused_equals_two_pass(fsr, port, shape):
+    """BASELINE config 4: the LDS-fused EASU->RCAS launch is bit-identical to the two dispatches with an
+    intermediary of the output's format, in both arithmetic modes, with every RCAS option; and (EXACT)
+    to the CPU oracle chain FsrEasuF -> binary16 -> FsrRcasF."""
+    iw, ih, ow, oh = shape
+    img = frames.synthetic_frame(iw, ih, k=6, dtype=np.float16)
+    src = dev(img)
+    con = fsr.FsrEasuCon(iw, ih, iw, ih, ow, oh)
+    rc = fsr.FsrRcasCon(0.25)
+    for dtype in (torch.float16, torch.float32):
+        s = src.to(dtype)
+        for math in (fsr.FLAG_MATH_EXACT, 0):
+            for opts in (0, fsr.FLAG_RCAS_DENOISE, fsr.FLAG_RCAS_PASSTHROUGH_ALPHA | fsr.FLAG_HDR_SQUARE):
+                mid = torch.zeros(oh, ow, 4, dtype=dtype, device="cuda")
+                two = torch.zeros_like(mid)
+                one = torch.full_like(mid, 3.0)
+                fsr.easu(s, mid, con=con, flags=math)
+                fsr.rcas(mid, two, con=rc, flags=math | opts)
+                fsr.easu_rcas_fused(s, one, easu_con=con, rcas_con=rc, flags=math | opts)
+                torch.cuda.synchronize()
+                assert torch.equal(one.view(torch.int16 if dtype == torch.float16 else torch.int32),
+                                   two.view(torch.int16 if dtype == torch.float16 else torch.int32)), (dtype, math, opts)
+    want_mid = port.easu_f(img.astype(np.float32), ow, oh, con).astype(np.float16).astype(np.float32)
+    want = port.rcas_f(want_mid, rc)
+    out = torch.zeros(oh, ow, 4, dtype=torch.float16, device="cuda")
+    fsr.easu_rcas_fused(src, out, easu_con=con, rcas_con=rc, flags=fsr.FLAG_MATH_EXACT)
+    assert_exact16(host(out), want, "fused EXACT vs oracle chain")
+
+
+def test_fused_through_upscale(fsr, port):
+    iw, ih, ow, oh = 160, 90, 320, 180
+    img = frames.synthetic_frame(iw, ih, k=4, dtype=np.float16)
+    src = dev(img)
+    dst = torch.zeros(oh, ow, 4, dtype=torch.float16, device="cuda")
+    filt = fsr.FSR_Filter()
+    filt.OnCreate(slowFallback=True, exact=True, fused=True)
+    filt.OnCreateWindowSizeDependentResources(src, dst, ow, oh)
+    filt.Upscale(ow, oh, fsr.State(iw, ih, bUseRcas=True, rcasAttenuation=0.25))
+    con = port.FsrEasuCon(iw, ih, iw, ih, ow, oh)
+    mid = port.easu_f(img.astype(np.float32), ow, oh, con).astype(np.float16).astype(np.float32)
+    assert_exact16(host(dst), port.rcas_f(mid, port.FsrRcasCon(0.25)), "fused Upscale")
+    assert filt.m_intermediary is None
+
+
 # ------------------------------------------------------------------------------------------------
 # BASELINE.json full sizes: oracle on row bands + size-independent properties
 # ------------------------------------------------------------------------------------------------
