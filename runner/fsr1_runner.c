@@ -1,0 +1,268 @@
+/*
+ * fsr1_runner — plain-C host runner for the MI355X FSR 1.0 path (EASU + RCAS), the counterpart of the
+ * reference's DX12/Vulkan sample dispatch (sample/src/DX12/FSR_Filter.cpp:101-141 driven by
+ * SampleRenderer::OnRender, SampleRenderer.cpp:705-709) without the renderer around it.
+ *
+ * One process, one host thread per GPU.  Frames are independent (FSR 1.0 keeps no history), so a
+ * batch of F frames is sharded in contiguous blocks over the GPUs; every thread uploads its frames once,
+ * then runs K timed steps of  FsrEasuCon -> EASU -> FsrRcasCon -> RCAS  over its block through the C ABI of
+ * libfsr1_hip.so, timing with HIP events on its own stream.  The only inter-GPU traffic is one RCCL
+ * all-gather of the per-GPU throughput counters {frames, output pixels, device ns} over xGMI; no image
+ * data ever crosses a link.  Rank 0 prints one JSON line.
+ *
+ *   fsr1_runner [--gpus N] [--frames F] [--in WxH] [--out WxH] [--steps K] [--warmup W]
+ *               [--pipeline two-pass|fused|easu] [--math f|exact] [--sharpness STOPS] [--hdr]
+ */
+#define __HIP_PLATFORM_AMD__ 1
+#include <hip/hip_runtime_api.h>
+#include <math.h>
+#include <pthread.h>
+#include <rccl/rccl.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "fsr1_hip.h"
+
+typedef struct {
+  int gpus, frames, in_w, in_h, out_w, out_h, steps, warmup, hdr;
+  int pipeline; /* 0 two-pass, 1 fused, 2 easu only */
+  uint32_t math;
+  float sharpness;
+} options_t;
+
+typedef struct {
+  const options_t* opt;
+  int rank;
+  ncclComm_t comm;
+  /* results */
+  uint64_t counters[3];  /* frames, output pixels, device nanoseconds (timed region) */
+  uint64_t* gathered;    /* rank 0: [gpus][3] */
+  int status;
+  char error[256];
+} worker_t;
+
+#define HIP_OK(w, call)                                                                          \
+  do {                                                                                           \
+    hipError_t e_ = (call);                                                                      \
+    if (e_ != hipSuccess) {                                                                      \
+      snprintf((w)->error, sizeof (w)->error, "%s: %s", #call, hipGetErrorString(e_));           \
+      (w)->status = -1;                                                                          \
+      return NULL;                                                                               \
+    }                                                                                            \
+  } while (0)
+#define FSR_OK(w, call)                                                                          \
+  do {                                                                                           \
+    int rc_ = (call);                                                                            \
+    if (rc_ != 0) {                                                                              \
+      snprintf((w)->error, sizeof (w)->error, "%s: %s", #call, fsr1_last_error());               \
+      (w)->status = rc_;                                                                         \
+      return NULL;                                                                               \
+    }                                                                                            \
+  } while (0)
+#define NCCL_OK(w, call)                                                                         \
+  do {                                                                                           \
+    ncclResult_t r_ = (call);                                                                    \
+    if (r_ != ncclSuccess) {                                                                     \
+      snprintf((w)->error, sizeof (w)->error, "%s: %s", #call, ncclGetErrorString(r_));          \
+      (w)->status = -2;                                                                          \
+      return NULL;                                                                               \
+    }                                                                                            \
+  } while (0)
+
+/* float -> binary16, round to nearest even (storage conversion of the synthetic frames) */
+static uint16_t half_from_float(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  const uint32_t sign = (u >> 16) & 0x8000u;
+  u &= 0x7fffffffu;
+  if (u >= 0x7f800000u) return (uint16_t)(sign | (u > 0x7f800000u ? 0x7e00u : 0x7c00u));
+  if (u >= 0x477ff000u) return (uint16_t)(sign | 0x7c00u); /* rounds to infinity */
+  if (u < 0x33000001u) return (uint16_t)sign;               /* rounds to zero */
+  int32_t e = (int32_t)(u >> 23) - 127;
+  uint32_t m = (u & 0x7fffffu) | 0x800000u;
+  int shift = e < -14 ? 13 + (-14 - e) : 13;
+  uint32_t h = m >> shift, rem = m & ((1u << shift) - 1u), half = 1u << (shift - 1);
+  if (rem > half || (rem == half && (h & 1u))) ++h;
+  if (e < -14) return (uint16_t)(sign | h);
+  return (uint16_t)(sign | (((uint32_t)(e + 15) << 10) + (h - 0x400u)));
+}
+
+static uint32_t mix32(uint32_t x, uint32_t y, uint32_t seed) {
+  uint32_t s = (x * 73856093u) ^ (y * 19349663u) ^ seed;
+  for (int i = 0; i < 2; ++i) { s = s * 1664525u + 1013904223u; s ^= s >> 15; }
+  return s;
+}
+
+/* Deterministic synthetic frame k: diagonal hard-edge stripes + per-channel sinusoids + hash noise, in [0,1]. */
+static void synth_frame(uint16_t* dst, int w, int h, int k) {
+  const uint32_t seed = 0x9E3779B9u * (uint32_t)(k + 1);
+  static const float ax[3] = {0.031f, 0.013f, 0.023f}, ay[3] = {0.017f, 0.029f, 0.011f}, ph[3] = {0.0f, 1.3f, 2.1f};
+  for (int y = 0; y < h; ++y)
+    for (int x = 0; x < w; ++x) {
+      const float stripes = ((x + 2 * y + k) % 16) < 8 ? 0.8f : 0.1f;
+      uint16_t* p = dst + ((size_t)y * w + x) * 4;
+      for (int c = 0; c < 3; ++c) {
+        float smooth = 0.5f + 0.5f * sinf((float)x * ax[c] + (float)y * ay[c] + ph[c] + 0.37f * (float)k);
+        float noise = (float)(mix32((uint32_t)x, (uint32_t)y, seed + 0x1234567u * (uint32_t)(c + 1)) >> 8) * (1.0f / 16777216.0f) * 0.1f;
+        float v = 0.55f * stripes + 0.35f * smooth + noise;
+        p[c] = half_from_float(v < 0.f ? 0.f : (v > 1.f ? 1.f : v));
+      }
+      p[3] = 0x3c00; /* 1.0 */
+    }
+}
+
+static void shard(int total, int rank, int world, int* begin, int* end) {
+  const int q = total / world, r = total % world;
+  *begin = rank * q + (rank < r ? rank : r);
+  *end = *begin + q + (rank < r ? 1 : 0);
+}
+
+static void* worker(void* arg) {
+  worker_t* w = (worker_t*)arg;
+  const options_t* o = w->opt;
+  int f0, f1;
+  shard(o->frames, w->rank, o->gpus, &f0, &f1);
+  const int nf = f1 - f0;
+  HIP_OK(w, hipSetDevice(w->rank));
+  hipStream_t stream;
+  HIP_OK(w, hipStreamCreate(&stream));
+
+  const size_t in_frame = (size_t)o->in_w * o->in_h * 8, out_frame = (size_t)o->out_w * o->out_h * 8;
+  void *d_in = NULL, *d_mid = NULL, *d_out = NULL;
+  if (nf > 0) {
+    HIP_OK(w, hipMalloc(&d_in, in_frame * nf));
+    HIP_OK(w, hipMalloc(&d_out, out_frame * nf));
+    if (o->pipeline == 0) HIP_OK(w, hipMalloc(&d_mid, out_frame * nf));
+    uint16_t* host = (uint16_t*)malloc(in_frame);
+    if (!host) { snprintf(w->error, sizeof w->error, "out of host memory"); w->status = -1; return NULL; }
+    for (int f = 0; f < nf; ++f) {
+      synth_frame(host, o->in_w, o->in_h, f0 + f);
+      HIP_OK(w, hipMemcpy((char*)d_in + in_frame * f, host, in_frame, hipMemcpyHostToDevice));
+    }
+    free(host);
+  }
+  fsr1_image in = {d_in, o->in_w, o->in_h, FSR1_FORMAT_RGBA16F, nf, 0, 0};
+  fsr1_image mid = {d_mid, o->out_w, o->out_h, FSR1_FORMAT_RGBA16F, nf, 0, 0};
+  fsr1_image out = {d_out, o->out_w, o->out_h, FSR1_FORMAT_RGBA16F, nf, 0, 0};
+  fsr1_params p;
+  memset(&p, 0, sizeof p);
+  p.render_width = (float)o->in_w;
+  p.render_height = (float)o->in_h;
+  p.use_rcas = o->pipeline != 2;
+  p.rcas_attenuation = o->sharpness;
+  p.hdr = o->hdr;
+  p.fused = o->pipeline == 1;
+  p.flags = o->math;
+
+  hipEvent_t ev0, ev1;
+  HIP_OK(w, hipEventCreate(&ev0));
+  HIP_OK(w, hipEventCreate(&ev1));
+  float ms = 0.f;
+  if (nf > 0) {
+    for (int i = 0; i < o->warmup; ++i) FSR_OK(w, fsr1_upscale(&in, o->pipeline == 0 ? &mid : NULL, &out, &p, stream));
+    HIP_OK(w, hipEventRecord(ev0, stream));
+    for (int i = 0; i < o->steps; ++i) FSR_OK(w, fsr1_upscale(&in, o->pipeline == 0 ? &mid : NULL, &out, &p, stream));
+    HIP_OK(w, hipEventRecord(ev1, stream));
+    HIP_OK(w, hipEventSynchronize(ev1));
+    HIP_OK(w, hipEventElapsedTime(&ms, ev0, ev1));
+  }
+  w->counters[0] = (uint64_t)nf * (uint64_t)o->steps;
+  w->counters[1] = w->counters[0] * (uint64_t)o->out_w * (uint64_t)o->out_h;
+  w->counters[2] = (uint64_t)((double)ms * 1e6);
+
+  /* the one collective: all-gather of 3 x uint64 per GPU over RCCL */
+  uint64_t *d_send = NULL, *d_recv = NULL;
+  HIP_OK(w, hipMalloc((void**)&d_send, sizeof w->counters));
+  HIP_OK(w, hipMalloc((void**)&d_recv, sizeof w->counters * o->gpus));
+  HIP_OK(w, hipMemcpyAsync(d_send, w->counters, sizeof w->counters, hipMemcpyHostToDevice, stream));
+  NCCL_OK(w, ncclAllGather(d_send, d_recv, 3, ncclUint64, w->comm, stream));
+  HIP_OK(w, hipStreamSynchronize(stream));
+  if (w->rank == 0) HIP_OK(w, hipMemcpy(w->gathered, d_recv, sizeof w->counters * o->gpus, hipMemcpyDeviceToHost));
+
+  (void)hipFree(d_send); (void)hipFree(d_recv);
+  (void)hipFree(d_in); (void)hipFree(d_mid); (void)hipFree(d_out);
+  (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1);
+  (void)hipStreamDestroy(stream);
+  return NULL;
+}
+
+static int parse_size(const char* s, int* w, int* h) { return sscanf(s, "%dx%d", w, h) == 2 && *w > 0 && *h > 0; }
+
+static void usage(void) {
+  puts("usage: fsr1_runner [--gpus N] [--frames F] [--in WxH] [--out WxH] [--steps K] [--warmup W]\n"
+       "                   [--pipeline two-pass|fused|easu] [--math f|exact] [--sharpness STOPS] [--hdr]\n"
+       "defaults: 1 GPU, 1 frame per GPU, 1920x1080 -> 3840x2160, 100 steps, 10 warmup, two-pass, f, 0.25 stops");
+}
+
+int main(int argc, char** argv) {
+  options_t o = {1, 0, 1920, 1080, 3840, 2160, 100, 10, 0, 0, 0u, 0.25f};
+  for (int i = 1; i < argc; ++i) {
+    const char* a = argv[i];
+    const char* v = i + 1 < argc ? argv[i + 1] : NULL;
+    if (!strcmp(a, "--help") || !strcmp(a, "-h")) { usage(); return 0; }
+    else if (!strcmp(a, "--hdr")) o.hdr = 1;
+    else if (!v) { fprintf(stderr, "missing value for %s\n", a); return 2; }
+    else if (!strcmp(a, "--gpus")) { o.gpus = atoi(v); ++i; }
+    else if (!strcmp(a, "--frames")) { o.frames = atoi(v); ++i; }
+    else if (!strcmp(a, "--steps")) { o.steps = atoi(v); ++i; }
+    else if (!strcmp(a, "--warmup")) { o.warmup = atoi(v); ++i; }
+    else if (!strcmp(a, "--sharpness")) { o.sharpness = (float)atof(v); ++i; }
+    else if (!strcmp(a, "--in")) { if (!parse_size(v, &o.in_w, &o.in_h)) { fprintf(stderr, "bad --in %s\n", v); return 2; } ++i; }
+    else if (!strcmp(a, "--out")) { if (!parse_size(v, &o.out_w, &o.out_h)) { fprintf(stderr, "bad --out %s\n", v); return 2; } ++i; }
+    else if (!strcmp(a, "--pipeline")) {
+      if (!strcmp(v, "two-pass")) o.pipeline = 0; else if (!strcmp(v, "fused")) o.pipeline = 1; else if (!strcmp(v, "easu")) o.pipeline = 2;
+      else { fprintf(stderr, "bad --pipeline %s\n", v); return 2; }
+      ++i;
+    } else if (!strcmp(a, "--math")) {
+      if (!strcmp(v, "f")) o.math = 0; else if (!strcmp(v, "exact")) o.math = FSR1_FLAG_MATH_EXACT;
+      else { fprintf(stderr, "bad --math %s\n", v); return 2; }
+      ++i;
+    } else { fprintf(stderr, "unknown option %s\n", a); usage(); return 2; }
+  }
+  if (o.gpus < 1 || o.steps < 1 || o.warmup < 0) { usage(); return 2; }
+  if (o.frames <= 0) o.frames = o.gpus; /* one frame per GPU */
+  const int visible = fsr1_device_count();
+  if (visible < o.gpus) { fprintf(stderr, "need %d GPUs, %d visible (%s)\n", o.gpus, visible, visible < 0 ? fsr1_last_error() : "ok"); return 1; }
+
+  ncclComm_t* comms = (ncclComm_t*)calloc((size_t)o.gpus, sizeof *comms);
+  int* devs = (int*)calloc((size_t)o.gpus, sizeof *devs);
+  for (int i = 0; i < o.gpus; ++i) devs[i] = i;
+  ncclResult_t nr = ncclCommInitAll(comms, o.gpus, devs);
+  if (nr != ncclSuccess) { fprintf(stderr, "ncclCommInitAll: %s\n", ncclGetErrorString(nr)); return 1; }
+
+  worker_t* ws = (worker_t*)calloc((size_t)o.gpus, sizeof *ws);
+  pthread_t* th = (pthread_t*)calloc((size_t)o.gpus, sizeof *th);
+  uint64_t* gathered = (uint64_t*)calloc((size_t)o.gpus * 3, sizeof *gathered);
+  for (int i = 0; i < o.gpus; ++i) {
+    ws[i].opt = &o; ws[i].rank = i; ws[i].comm = comms[i]; ws[i].gathered = gathered;
+    pthread_create(&th[i], NULL, worker, &ws[i]);
+  }
+  int rc = 0;
+  for (int i = 0; i < o.gpus; ++i) {
+    pthread_join(th[i], NULL);
+    if (ws[i].status) { fprintf(stderr, "gpu %d: %s\n", i, ws[i].error); rc = 1; }
+  }
+  if (!rc) {
+    uint64_t frames = 0, pixels = 0, max_ns = 0;
+    for (int i = 0; i < o.gpus; ++i) {
+      frames += gathered[3 * i]; pixels += gathered[3 * i + 1];
+      if (gathered[3 * i + 2] > max_ns) max_ns = gathered[3 * i + 2];
+    }
+    const double sec = (double)max_ns * 1e-9;
+    const size_t in_b = (size_t)o.in_w * o.in_h * 8, out_b = (size_t)o.out_w * o.out_h * 8;
+    const double bytes = (double)frames * (double)(o.pipeline == 0 ? in_b + 3 * out_b : in_b + out_b);
+    printf("{\"metric\": \"upscaled megapixels/sec\", \"value\": %.1f, \"unit\": \"Mpix/s\", \"n_gpus\": %d, \"frames\": %llu, "
+           "\"steps\": %d, \"seconds\": %.6f, \"in\": \"%dx%d\", \"out\": \"%dx%d\", \"pipeline\": \"%s\", \"math\": \"%s\", "
+           "\"algorithmic_GBps\": %.1f, \"hbm_peak_frac\": %.4f, \"per_gpu_ms\": [",
+           (double)pixels / sec / 1e6, o.gpus, (unsigned long long)frames, o.steps, sec, o.in_w, o.in_h, o.out_w, o.out_h,
+           o.pipeline == 0 ? "two-pass" : (o.pipeline == 1 ? "fused" : "easu"), o.math ? "exact" : "f", bytes / sec / 1e9,
+           bytes / sec / 1e9 / (8000.0 * o.gpus));
+    for (int i = 0; i < o.gpus; ++i) printf("%s%.3f", i ? ", " : "", (double)gathered[3 * i + 2] * 1e-6);
+    printf("]}\n");
+  }
+  for (int i = 0; i < o.gpus; ++i) ncclCommDestroy(comms[i]);
+  free(comms); free(devs); free(ws); free(th); free(gathered);
+  return rc;
+}

@@ -1,0 +1,36 @@
+"""The plain-C host runner (runner/fsr1_runner.c): builds against the C ABI; on a GPU box it runs the
+two-pass and fused pipelines and reports the counters it gathered over RCCL."""
+import json
+import os
+import subprocess
+
+import pytest
+
+from conftest import ROOT
+
+RUNNER = os.path.join(ROOT, "runner", "fsr1_runner")
+
+
+@pytest.fixture(scope="module")
+def runner(fsr):
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "runner")], stdout=subprocess.DEVNULL)
+    return RUNNER
+
+
+def test_runner_builds_and_parses_arguments(runner):
+    out = subprocess.run([runner, "--help"], capture_output=True, text=True)
+    assert out.returncode == 0 and "--pipeline" in out.stdout
+    assert subprocess.run([runner, "--pipeline", "nope"], capture_output=True).returncode == 2
+    assert subprocess.run([runner, "--in", "12by7"], capture_output=True).returncode == 2
+    assert subprocess.run([runner, "--bogus", "1"], capture_output=True).returncode == 2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pipeline", ["two-pass", "fused", "easu"])
+def test_runner_on_gpu(runner, pipeline):
+    out = subprocess.run([runner, "--gpus", "1", "--frames", "3", "--in", "640x360", "--out", "1280x720", "--steps", "20",
+                          "--warmup", "3", "--pipeline", pipeline], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    d = json.loads(out.stdout.strip().splitlines()[-1])
+    assert d["n_gpus"] == 1 and d["frames"] == 60 and d["pipeline"] == pipeline
+    assert d["value"] > 1000.0  # Mpix/s; the CPU reference does ~25 on 128 cores
