@@ -49,6 +49,26 @@ def reduce_counters(frames, pixels, seconds, device):
     return {"frames": int(round(s[0].item())), "pixels": int(round(s[1].item())), "seconds": float(m[0].item())}
 
 
+def pmc_traffic(workload, pipeline, kernel_name):
+    """HBM bytes per launch of `kernel_name` from the newest committed rocprofv3 PMC summary of this
+    workload/pipeline (profiles/*.json, written by tools/prof_summary.py from separate --pmc passes of this
+    very command; FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 correction, WRITE_SIZE as reported).
+    PMC counters cannot be collected from inside the timed run, so this is None when no summary matches."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*.json"))):
+        try:
+            d = json.load(open(f))
+        except (OSError, ValueError):
+            continue
+        if d.get("workload") != workload or d.get("pipeline") != pipeline:
+            continue
+        for k, v in d.get("kernels", {}).items():
+            if ("::%s_kernel<" % kernel_name) in k and "traffic_bytes" in v.get("hbm_per_launch", {}):
+                best = (v["hbm_per_launch"]["traffic_bytes"], os.path.relpath(f, ROOT))
+    return best
+
+
 def cpu_baseline(fsr, in_w, in_h, out_w, out_h, target_seconds=12.0):
     """The reference path on the host cores: oracle/_ref (the reference headers compiled verbatim; kind
     "reference") when it travelled with the tree, else the plain-C restatement (kind "port"); OpenMP over
@@ -189,8 +209,10 @@ def main():
 
     def roof(name):
         gbps = alg[name] / (kern[name] * 1e-3) / 1e9
+        pmc = pmc_traffic(args.workload, args.pipeline, name) if args.math == "f" else None
         return {"kernel": name, "bound": "hbm", "achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": round(gbps / HBM_PEAK_GBPS, 4), "traffic": None, "algorithmic_bytes": alg[name],
+                "frac": round(gbps / HBM_PEAK_GBPS, 4), "traffic": pmc[0] if pmc else None,
+                "traffic_source": pmc[1] if pmc else None, "algorithmic_bytes": alg[name],
                 "avg_kernel_us": round(kern[name] * 1e3, 2)}
 
     if rank == 0:

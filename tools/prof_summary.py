@@ -24,7 +24,49 @@ def kernel_key(name):
     return name.split("(")[0].replace("void ", "").strip()
 
 
+def _dbs(d):
+    return glob.glob(os.path.join(d, "**", "*_results.db"), recursive=True)
+
+
+def read_stats_db(d):
+    """rocpd (sqlite) output of rocprofv3: per-kernel duration statistics from the `kernels` view."""
+    import sqlite3
+    import statistics
+    out = {}
+    for f in _dbs(d):
+        c = sqlite3.connect(f)
+        rows = collections.defaultdict(list)
+        meta = {}
+        for name, dur, gx, wx, lds, scr, vg, ag, sg in c.execute(
+                "select name, duration, grid_x, workgroup_x, lds_size, scratch_size, vgpr_count, accum_vgpr_count, sgpr_count from kernels"):
+            if "fsr1::" not in name:
+                continue
+            k = kernel_key(name)
+            rows[k].append(dur)
+            meta.setdefault(k, {"vgpr": vg, "agpr": ag, "sgpr": sg, "lds_bytes": lds, "scratch": scr, "workgroup": wx, "grid": gx})
+        total = sum(sum(v) for v in rows.values()) or 1
+        for k, v in rows.items():
+            out[k] = {"calls": len(v), "avg_us": round(sum(v) / len(v) / 1e3, 3), "min_us": round(min(v) / 1e3, 3),
+                      "max_us": round(max(v) / 1e3, 3), "stddev_us": round(statistics.pstdev(v) / 1e3, 3),
+                      "percent_of_fsr1_time": round(100.0 * sum(v) / total, 2)}
+            out[k].update(meta[k])
+    return out
+
+
+def read_pmc_db(d):
+    import sqlite3
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for f in _dbs(d):
+        c = sqlite3.connect(f)
+        for name, ctr, val in c.execute("select kernel_name, counter_name, value from counters_collection"):
+            if "fsr1::" in name:
+                agg[kernel_key(name)][ctr].append(float(val))
+    return {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in agg.items()}
+
+
 def read_stats(d):
+    if _dbs(d):
+        return read_stats_db(d)
     out = {}
     for f in glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
@@ -51,6 +93,8 @@ def read_stats(d):
 
 
 def read_pmc(d):
+    if _dbs(d):
+        return read_pmc_db(d)
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
@@ -67,6 +111,8 @@ def main():
     ap.add_argument("--pmc", action="append", default=[])
     ap.add_argument("--note", default="")
     ap.add_argument("--command", default="")
+    ap.add_argument("--workload", default="", help="bench.py --workload this profile belongs to (lets bench.py find its PMC traffic)")
+    ap.add_argument("--pipeline", default="", help="bench.py --pipeline this profile belongs to")
     a = ap.parse_args()
 
     kernels = read_stats(a.stats)
@@ -92,7 +138,7 @@ def main():
         if "SQ_INSTS_VALU" in p and "avg_us" in v:
             # wave-instructions per SIMD per microsecond: 1024 SIMDs; a plain v_fma_f32 stream peaks at ~1000/us (2.4 cyc @2.4 GHz)
             v["valu_wave_insts_per_simd_per_us"] = round(p["SQ_INSTS_VALU"] / 1024.0 / v["avg_us"], 1)
-    doc = {"command": a.command, "note": a.note, "kernels": kernels}
+    doc = {"command": a.command, "note": a.note, "workload": a.workload, "pipeline": a.pipeline, "kernels": kernels}
     os.makedirs(os.path.dirname(a.out) or ".", exist_ok=True)
     with open(a.out + ".json", "w") as f:
         json.dump(doc, f, indent=1, sort_keys=True)
