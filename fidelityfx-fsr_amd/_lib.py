@@ -52,6 +52,7 @@ SYMBOLS = {
     "fsr1_last_error": (ctypes.c_char_p, []),
     "fsr1_version": (ctypes.c_int, []),
     "fsr1_device_count": (ctypes.c_int, []),
+    "fsr1_selftest": (ctypes.c_int, [_U32P]),
     "fsr1_timer_create": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p)]),
     "fsr1_timer_start": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     "fsr1_timer_stop": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),

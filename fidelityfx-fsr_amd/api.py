@@ -208,6 +208,14 @@ class FSR_Filter:
         return self._output
 
 
+def selftest():
+    """Number of binary16 operands (of 65536) for which the packed-fp16 kernels' reciprocal is not the
+    correctly rounded 1/x; 0 on a conforming device."""
+    n = ctypes.c_uint32(0)
+    _lib.check(_lib.load().fsr1_selftest(ctypes.byref(n)))
+    return int(n.value)
+
+
 class Timer:
     """HIP-event stopwatch of the C ABI (fsr1_timer_*), recording on the stream the kernels use."""
 

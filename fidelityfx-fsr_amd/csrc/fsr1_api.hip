@@ -22,6 +22,19 @@ hipError_t rcas_h_launch(const RcasArgs& a, hipStream_t stream);
 
 using namespace fsr1;
 
+// fsr1_selftest: hardware assumptions of the packed-binary16 kernels, checked exhaustively over all 65536 operands.
+//   bit 0 of a failing operand's entry: half_rcp(x) != RTNE(IEEE binary32 1.0f/x)
+__global__ void selftest_kernel(uint32_t* failures) {
+  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= 65536u) return;
+  const half_t x = __builtin_bit_cast(half_t, (unsigned short)p);
+  const half_t fast = half_rcp(x);
+  const half_t ieee = (half_t)(1.0f / (float)x);  // correctly rounded binary32 division (hipcc default), then RTNE
+  const unsigned short fb = __builtin_bit_cast(unsigned short, fast), ib = __builtin_bit_cast(unsigned short, ieee);
+  const bool both_nan = (fast != fast) && (ieee != ieee);
+  if (fb != ib && !both_nan) atomicAdd(failures, 1u);
+}
+
 static thread_local char g_err[512] = "";
 
 static int fail(int code, const char* fmt, ...) {
@@ -217,6 +230,22 @@ int fsr1_upscale(const fsr1_image* in, const fsr1_image* intermediary, const fsr
   if (rc) return rc;
   // :130 the UAV->SRV barrier is stream order here
   return fsr1_rcas_dispatch(intermediary, out, rcas_con, rcas_flags, stream);  // :131
+}
+
+int fsr1_selftest(uint32_t* failures) {
+  if (!failures) return fail(FSR1_ERR_INVALID_ARGUMENT, "selftest: null");
+  uint32_t* d = nullptr;
+  hipError_t e = hipMalloc(&d, sizeof(uint32_t));
+  if (e != hipSuccess) return hip_fail(e, "hipMalloc");
+  e = hipMemset(d, 0, sizeof(uint32_t));
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(selftest_kernel, dim3(256), dim3(256), 0, nullptr, d);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpy(failures, d, sizeof(uint32_t), hipMemcpyDeviceToHost);
+  (void)hipFree(d);
+  if (e != hipSuccess) return hip_fail(e, "selftest");
+  return FSR1_OK;
 }
 
 // ---- HIP-event stopwatch ----

@@ -95,6 +95,12 @@ __device__ __forceinline__ float pinned(float x) { asm volatile("" : "+v"(x)); r
 // RTNE float -> binary16 (v_cvt_f16_f32 under the default rounding mode; never cvt_pkrtz).
 __device__ __forceinline__ half_t to_half(float f) { return (half_t)f; }
 
+// ARcpH1 (GLSL `1.0/x`, ffx_a.h:1005) — the binary16 reciprocal, correctly rounded: v_rcp_f32 (1 ulp in binary32)
+// of the widened operand, narrowed RTNE.  That this equals the correctly rounded quotient for every one of the
+// 65536 binary16 operands is checked on the device by fsr1_selftest() (an IEEE binary32 division narrowed
+// to binary16 is correctly rounded because 24 >= 2*11+2; v_rcp_f16 and LLVM's f16 `1.0/x` are not).
+__device__ __forceinline__ half_t half_rcp(half_t a) { return (half_t)__builtin_amdgcn_rcpf((float)a); }
+
 template <int FMT> struct Pixel;  // FMT = fsr1_format
 template <> struct Pixel<FSR1_FORMAT_RGBA16F> {
   typedef half4_t T;

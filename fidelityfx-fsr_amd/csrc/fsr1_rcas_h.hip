@@ -1,0 +1,166 @@
+// RCAS, packed binary16 arithmetic — FsrRcasHx2 (ffx-fsr/ffx_fsr1.h:888-984), whose per-element
+// arithmetic is FsrRcasH (:782-866), for gfx950.
+//
+// Parity class "H": each lane sharpens TWO horizontally adjacent pixels in the two halves of packed
+// binary16 registers (the reference pairs pixels 8 columns apart, :913; the pairing does not enter the
+// arithmetic), one native binary16 operation per reference operation, contraction off — bit-identical
+// to the reference's FsrRcasH evaluated on the CPU with round-to-nearest-even after every operation.
+//
+// Streaming structure of the fp32 kernel (fsr1_rcas.hip): no LDS, a wave owns a 128-column x 24-row strip,
+// rows flow through registers (b = previous row, h = next row), the horizontal neighbours of a lane's
+// pixel pair are its own other pixel and the adjacent lane's facing pixel (DPP wave shift); lanes 0 / 63
+// also load the strip's apron column.  Loads outside the image are 0 (FSR_Pass.hlsl:61).
+#include "fsr1_device.h"
+
+namespace fsr1 {
+
+typedef unsigned short u16;
+
+constexpr int kRcasHRows = 24;
+constexpr int kRcasHCols = 128 * 4;  // columns per 256-thread workgroup
+constexpr int kShr1 = 0x138, kShl1 = 0x130;
+
+namespace {
+
+struct soa_t { half2_t r, g, b, a; };  // two pixels: .x = left (even column), .y = right
+
+__device__ __forceinline__ half2_t mx2(half2_t a, half2_t b) { return __builtin_elementwise_max(a, b); }
+__device__ __forceinline__ half2_t mn2(half2_t a, half2_t b) { return __builtin_elementwise_min(a, b); }
+__device__ __forceinline__ half2_t ab2(half2_t a) { return __builtin_elementwise_abs(a); }
+__device__ __forceinline__ half2_t s2(float v) { return half2_t{(half_t)v, (half_t)v}; }
+__device__ __forceinline__ half2_t rcp2(half2_t a) { return half2_t{half_rcp(a.x), half_rcp(a.y)}; }  // ARcpH2: correctly rounded
+// AMin3H2(x,y,z) = min(x, min(y, z)), ffx_a.h:1150 ; AMax3H2 likewise
+__device__ __forceinline__ half2_t mn3(half2_t x, half2_t y, half2_t z) { return mn2(x, mn2(y, z)); }
+__device__ __forceinline__ half2_t mx3(half2_t x, half2_t y, half2_t z) { return mx2(x, mx2(y, z)); }
+// APrxMedRcpH2, ffx_a.h:1816: b = bits(0x778d - bits(a)); b*(-b*a + 2)
+__device__ __forceinline__ half2_t prx_med_rcp2(half2_t a) {
+  typedef u16 u16x2 __attribute__((ext_vector_type(2)));
+  const u16x2 k = {0x778du, 0x778du};
+  const half2_t b = __builtin_bit_cast(half2_t, (u16x2)(k - __builtin_bit_cast(u16x2, a)));
+  return b * (-b * a + s2(2.0f));
+}
+
+template <int CTRL>
+__device__ __forceinline__ half2_t dpp2(half2_t keep, half2_t v) {
+  return __builtin_bit_cast(half2_t, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, keep), __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+
+}  // namespace
+
+// OPTS = false: plain pass, flags compiled out.
+template <bool OPTS>
+__global__ void __launch_bounds__(kThreads) rcas_h_kernel(const RcasArgs a) {
+  const uint32_t flags = OPTS ? a.flags : 0u;
+  const int tiles_per_frame = a.tiles_x * a.tiles_y;
+  const int t = xcd_swizzle(blockIdx.x, tiles_per_frame * a.frames);
+  const int frame = t / tiles_per_frame;
+  const int tf = t - frame * tiles_per_frame;
+  const int ty = tf / a.tiles_x, tx = tf - ty * a.tiles_x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int x0 = tx * kRcasHCols + wave * 128, y0 = ty * kRcasHRows;
+  if (x0 >= a.in.width) return;
+
+  const int W = a.in.width, H = a.in.height;
+  const int col = x0 + 2 * lane;
+  const bool ok0 = col < W, ok1 = col + 1 < W;
+  const int hcol = lane == 0 ? x0 - 1 : x0 + 128;
+  const bool halo_ok = (lane == 0 || lane == 63) && hcol >= 0 && hcol < W;
+  const char* const in_frame = a.in.base + (long long)frame * a.in.frame_stride;
+  char* const out_frame = a.out.base + (long long)frame * a.out.frame_stride;
+
+  // one row of this lane's pixel pair as structure-of-arrays, plus the apron texel broadcast to both halves
+  auto load = [&](int y, soa_t& own, soa_t& halo) {
+    half4_t p0 = {0, 0, 0, 0}, p1 = {0, 0, 0, 0}, ph = {0, 0, 0, 0};
+    if (y >= 0 && y < H) {  // wave-uniform
+      const char* const row = in_frame + (long long)y * a.in.pitch;
+      if (ok0) p0 = *reinterpret_cast<const half4_t*>(row + (size_t)col * 8);
+      if (ok1) p1 = *reinterpret_cast<const half4_t*>(row + (size_t)(col + 1) * 8);
+      if (halo_ok) ph = *reinterpret_cast<const half4_t*>(row + (size_t)hcol * 8);
+    }
+    own = soa_t{half2_t{p0.x, p1.x}, half2_t{p0.y, p1.y}, half2_t{p0.z, p1.z}, half2_t{p0.w, p1.w}};
+    halo = soa_t{half2_t{ph.x, ph.x}, half2_t{ph.y, ph.y}, half2_t{ph.z, ph.z}, half2_t{ph.w, ph.w}};
+  };
+
+  constexpr int kAhead = 3, kRing = kAhead + 1;
+  soa_t q[kRing], g[kRing];
+  soa_t prev;
+  {
+    soa_t g_prev;
+    load(y0 - 1, prev, g_prev);
+#pragma unroll
+    for (int k = 0; k < kAhead; ++k) load(y0 + k, q[k], g[k]);
+  }
+  // :857 sharpness = AH2_AU1(con.y).x — the packed half of con[1]
+  const half_t sharp1 = __builtin_bit_cast(half_t, (u16)(a.con[1] & 0xffffu));
+  const half2_t sharp = {sharp1, sharp1};
+  const half2_t hlf = s2(0.5f), qtr = s2(0.25f), four = s2(4.0f), one = s2(1.0f);
+
+#pragma unroll
+  for (int r = 0; r < kRcasHRows; ++r) {
+    const int y = y0 + r;
+    load(y + kAhead, q[(r + kAhead) % kRing], g[(r + kAhead) % kRing]);
+    const soa_t& e = q[r % kRing];
+    const soa_t& eh = g[r % kRing];
+    const soa_t& h = q[(r + 1) % kRing];
+    const soa_t& b = prev;
+    // d = (left neighbour's right pixel, own left pixel) ; f = (own right pixel, right neighbour's left pixel)
+    const half2_t nlR = dpp2<kShr1>(eh.r, e.r), nlG = dpp2<kShr1>(eh.g, e.g), nlB = dpp2<kShr1>(eh.b, e.b);
+    const half2_t nrR = dpp2<kShl1>(eh.r, e.r), nrG = dpp2<kShl1>(eh.g, e.g), nrB = dpp2<kShl1>(eh.b, e.b);
+    const half2_t dR = {nlR.y, e.r.x}, dG = {nlG.y, e.g.x}, dB = {nlB.y, e.b.x};
+    const half2_t fR = {e.r.y, nrR.x}, fG = {e.g.y, nrG.x}, fB = {e.b.y, nrB.x};
+    const half2_t bR = b.r, bG = b.g, bB = b.b, eR = e.r, eG = e.g, eB = e.b, hR = h.r, hG = h.g, hB = h.b;
+
+    // :946-951 min and max of ring
+    const half2_t mn4R = mn2(mn3(bR, dR, fR), hR), mn4G = mn2(mn3(bG, dG, fG), hG), mn4B = mn2(mn3(bB, dB, fB), hB);
+    const half2_t mx4R = mx2(mx3(bR, dR, fR), hR), mx4G = mx2(mx3(bG, dG, fG), hG), mx4B = mx2(mx3(bB, dB, fB), hB);
+    // :953-961 limiters (peakC = (1, -4))
+    const half2_t m4 = s2(-4.0f);
+    const half2_t hitMinR = mn2(mn4R, eR) * rcp2(four * mx4R);
+    const half2_t hitMinG = mn2(mn4G, eG) * rcp2(four * mx4G);
+    const half2_t hitMinB = mn2(mn4B, eB) * rcp2(four * mx4B);
+    const half2_t hitMaxR = (one - mx2(mx4R, eR)) * rcp2(four * mn4R + m4);
+    const half2_t hitMaxG = (one - mx2(mx4G, eG)) * rcp2(four * mn4G + m4);
+    const half2_t hitMaxB = (one - mx2(mx4B, eB)) * rcp2(four * mn4B + m4);
+    const half2_t lobeR = mx2(-hitMinR, hitMaxR), lobeG = mx2(-hitMinG, hitMaxG), lobeB = mx2(-hitMinB, hitMaxB);
+    half2_t lobe = mx2(s2(-(0.25f - (1.0f / 16.0f))), mn2(mx3(lobeR, lobeG, lobeB), s2(0.0f))) * sharp;
+    if (flags & FSR1_FLAG_RCAS_DENOISE) {  // :935-944, :969-971
+      const half2_t bL = bB * hlf + (bR * hlf + bG), dL = dB * hlf + (dR * hlf + dG), eL = eB * hlf + (eR * hlf + eG);
+      const half2_t fL = fB * hlf + (fR * hlf + fG), hL = hB * hlf + (hR * hlf + hG);
+      half2_t nz = qtr * bL + qtr * dL + qtr * fL + qtr * hL - eL;
+      nz = mn2(mx2(ab2(nz) * prx_med_rcp2(mx3(mx3(bL, dL, eL), fL, hL) - mn3(mn3(bL, dL, eL), fL, hL)), s2(0.0f)), one);
+      nz = s2(-0.5f) * nz + one;
+      lobe = lobe * nz;
+    }
+    // :973-976 resolve
+    const half2_t rcpL = prx_med_rcp2(four * lobe + one);
+    half2_t pR = (lobe * bR + lobe * dR + lobe * hR + lobe * fR + eR) * rcpL;
+    half2_t pG = (lobe * bG + lobe * dG + lobe * hG + lobe * fG + eG) * rcpL;
+    half2_t pB = (lobe * bB + lobe * dB + lobe * hB + lobe * fB + eB) * rcpL;
+    if (flags & FSR1_FLAG_HDR_SQUARE) { pR = pR * pR; pG = pG * pG; pB = pB * pB; }  // FSR_Pass.hlsl:92-93
+    const half2_t pA = (flags & FSR1_FLAG_RCAS_PASSTHROUGH_ALPHA) ? e.a : one;       // :905-907 / FSR_Pass.hlsl:94
+    if (y < H) {
+      char* const row = out_frame + (long long)y * a.out.pitch;
+      // FsrRcasDepackHx2 :880-886
+      if (ok0) *reinterpret_cast<half4_t*>(row + (size_t)col * 8) = half4_t{pR.x, pG.x, pB.x, pA.x};
+      if (ok1) *reinterpret_cast<half4_t*>(row + (size_t)(col + 1) * 8) = half4_t{pR.y, pG.y, pB.y, pA.y};
+    }
+    prev = e;
+  }
+}
+
+void rcas_h_geometry(int width, int height, int* tiles_x, int* tiles_y) {
+  *tiles_x = (width + kRcasHCols - 1) / kRcasHCols;
+  *tiles_y = (height + kRcasHRows - 1) / kRcasHRows;
+}
+
+hipError_t rcas_h_launch(const RcasArgs& a0, hipStream_t stream) {
+  RcasArgs a = a0;
+  rcas_h_geometry(a.in.width, a.in.height, &a.tiles_x, &a.tiles_y);  // its own strip shape (two pixels per lane)
+  const dim3 grid((unsigned)(a.tiles_x * a.tiles_y * a.frames)), block(kThreads);
+  const bool opts = (a.flags & (FSR1_FLAG_RCAS_DENOISE | FSR1_FLAG_RCAS_PASSTHROUGH_ALPHA | FSR1_FLAG_HDR_SQUARE)) != 0;
+  if (opts) hipLaunchKernelGGL(rcas_h_kernel<true>, grid, block, 0, stream, a);
+  else hipLaunchKernelGGL(rcas_h_kernel<false>, grid, block, 0, stream, a);
+  return hipGetLastError();
+}
+
+}  // namespace fsr1
