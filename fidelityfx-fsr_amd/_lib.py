@@ -7,7 +7,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfsr1_hip.so")
+LIB_PATH = os.environ.get("FSR1_HIP_LIB") or os.path.join(_HERE, "libfsr1_hip.so")  # env override: tuning experiments only
 
 _U32P = ctypes.POINTER(ctypes.c_uint32)
 _F = ctypes.c_float

@@ -13,7 +13,7 @@ namespace fsr1 {
 hipError_t easu_launch(const EasuArgs& a, int fmt, bool exact, hipStream_t stream);
 size_t easu_lds_bytes(int fmt, int fp_w, int fp_h);
 hipError_t rcas_launch(const RcasArgs& a, int fmt, bool exact, hipStream_t stream);
-void rcas_geometry(int width, int height, int* tiles_x, int* tiles_y);
+void rcas_geometry(int width, int height, int frames, int* tiles_x, int* tiles_y, int* rows);
 hipError_t fused_launch(const FusedArgs& a, int fmt, bool exact, hipStream_t stream);
 size_t fused_lds_bytes(int fmt, int fp_w, int fp_h);
 hipError_t easu_h_launch(const EasuArgs& a, hipStream_t stream);
@@ -162,7 +162,7 @@ int fsr1_rcas_dispatch(const fsr1_image* in, const fsr1_image* out, const uint32
                 in->frames, out->width, out->height, out->frames);
   if (overlaps(in, a.in, out, a.out)) return fail(FSR1_ERR_INVALID_ARGUMENT, "rcas: input and output overlap (RCAS cannot run in place)");
   memcpy(a.con, con, sizeof a.con);
-  rcas_geometry(out->width, out->height, &a.tiles_x, &a.tiles_y);
+  rcas_geometry(out->width, out->height, out->frames, &a.tiles_x, &a.tiles_y, &a.rows);
   a.frames = out->frames;
   a.flags = flags;
   hipError_t e;
@@ -194,12 +194,12 @@ int fsr1_easu_rcas_fused_dispatch(const fsr1_image* in, const fsr1_image* out, c
   memcpy(&sx, &easu_con[0], 4);
   memcpy(&sy, &easu_con[1], 4);
   a.fp_w = footprint_cap(kTileW + 2, sx);
-  a.fp_h = footprint_cap(kTileH + 2, sy);
+  a.fp_h = footprint_cap(kFusedTileH + 2, sy);
   if (a.fp_w < 0 || a.fp_h < 0) return fail(FSR1_ERR_INVALID_ARGUMENT, "fused: scale constants con0.xy = (%g, %g) are not usable", sx, sy);
   if (fused_lds_bytes(in->format, a.fp_w, a.fp_h) > 160 * 1024)
     return fail(FSR1_ERR_UNSUPPORTED, "fused: input/output ratio (%g, %g) needs more LDS than a CU has", sx, sy);
   a.tiles_x = (out->width + kTileW - 1) / kTileW;
-  a.tiles_y = (out->height + kTileH - 1) / kTileH;
+  a.tiles_y = (out->height + kFusedTileH - 1) / kFusedTileH;
   a.frames = out->frames;
   a.flags = flags;
   hipError_t e = fused_launch(a, in->format, (flags & FSR1_FLAG_MATH_EXACT) != 0, static_cast<hipStream_t>(stream));

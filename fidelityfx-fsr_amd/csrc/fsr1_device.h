@@ -23,6 +23,10 @@ typedef float float4_t __attribute__((ext_vector_type(4)));
 constexpr int kTileW = 64;
 constexpr int kTileH = 16;
 constexpr int kThreads = 256;
+#ifndef FSR1_FUSED_TILE_H
+#define FSR1_FUSED_TILE_H 16
+#endif
+constexpr int kFusedTileH = FSR1_FUSED_TILE_H;  // output rows per fused-kernel tile (multiple of 4)
 constexpr int kXcds = 8;  // MI355X: 8 XCDs, workgroup b is dispatched to XCD b % 8
 
 struct ImageView {
@@ -44,6 +48,7 @@ struct RcasArgs {
   ImageView in, out;
   uint32_t con[4];
   int tiles_x, tiles_y, frames;
+  int rows;  // rows per strip (a multiple of the kernel's row ring), chosen by the launcher
   uint32_t flags;
 };
 

@@ -17,7 +17,7 @@
 namespace fsr1 {
 
 constexpr int kMidW = kTileW + 2;
-constexpr int kMidH = kTileH + 2;
+constexpr int kMidH = kFusedTileH + 2;
 
 template <int FMT, bool EXACT>
 __global__ void __launch_bounds__(kThreads) fused_kernel(const FusedArgs a) {
@@ -32,14 +32,14 @@ __global__ void __launch_bounds__(kThreads) fused_kernel(const FusedArgs a) {
   const int frame = t / tiles_per_frame;
   const int tf = t - frame * tiles_per_frame;
   const int ty = tf / a.tiles_x, tx = tf - ty * a.tiles_x;
-  const int ox0 = tx * kTileW, oy0 = ty * kTileH;
+  const int ox0 = tx * kTileW, oy0 = ty * kFusedTileH;
   const int W = a.out.width, H = a.out.height;
 
   const float c0x = as_f32(a.easu_con[0]), c0y = as_f32(a.easu_con[1]), c0z = as_f32(a.easu_con[2]), c0w = as_f32(a.easu_con[3]);
 
   // apron tile = output pixels [ox0-1, ox0+64] x [oy0-1, oy0+16], clipped to the image for the footprint
   const int ax0 = max(ox0 - 1, 0), ay0 = max(oy0 - 1, 0);
-  const int axl = min(ox0 + kTileW, W - 1), ayl = min(oy0 + kTileH, H - 1);
+  const int axl = min(ox0 + kTileW, W - 1), ayl = min(oy0 + kFusedTileH, H - 1);
   const int fx0 = (int)floorf((float)ax0 * c0x + c0z) - 1;
   const int fy0 = (int)floorf((float)ay0 * c0y + c0w) - 1;
   const int fw = min((int)floorf((float)axl * c0x + c0z) + 2 - fx0 + 1, a.fp_w);
@@ -75,9 +75,9 @@ __global__ void __launch_bounds__(kThreads) fused_kernel(const FusedArgs a) {
   const uint32_t flags = a.flags;
   char* const out_col = a.out.base + (long long)frame * a.out.frame_stride + (size_t)ox * sizeof(texel_t);
   auto rgb = [](const texel_t& p) { const float4_t c = Pixel<FMT>::load(p); return rgb_t{c.x, c.y, c.z}; };
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int ry = wave * 4 + r;
+#pragma unroll 4
+  for (int r = 0; r < kFusedTileH / 4; ++r) {
+    const int ry = wave * (kFusedTileH / 4) + r;
     const int oy = oy0 + ry;
     if (oy >= H) break;
     const texel_t* const c = mid + (ry + 1) * kMidW + (lane + 1);
