@@ -2,6 +2,7 @@
 // reporting.  The host logic mirrors FSR_Filter::Upscale (sample/src/DX12/FSR_Filter.cpp:101-141).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -82,13 +83,25 @@ static bool overlaps(const fsr1_image* a, const ImageView& va, const fsr1_image*
   return a0 < b1 && b0 < a1;
 }
 
-// Largest number of input texels per axis any 64- (or 16-) pixel-wide output tile can touch:
-// fp(last) - fp(first) + 4 with fp(x) = floor(x*scale + bias); +1 for rounding slop.
-static int footprint_cap(int tile, float scale) {
-  if (!(scale > 0.0f) || !std::isfinite(scale)) return -1;
-  const double span = (double)(tile - 1) * (double)scale;
-  if (span > 4096.0) return -1;
-  return (int)std::floor(span) + 6;
+// Exact size of the largest input footprint any output tile touches along one axis, evaluated with the very
+// float arithmetic the kernels use for it (fp = floor(o*scale + bias), product and sum rounded separately):
+//   tile [o0, ol] reads texels fp(o0)-1 .. fp(ol)+2.
+// `apron` = 1 for the fused kernel, whose tiles compute one extra pixel on each side (clipped to the image).
+// Exactness matters: LDS per workgroup decides how many workgroups a CU holds (35x11 texels x 48 B lets 8 of them
+// in at 2x; two texels of slack per axis would leave 6).
+static int footprint_extent(int out_size, int tile, int apron, float scale, float bias) {
+  if (!(scale > 0.0f) || !std::isfinite(scale) || !std::isfinite(bias)) return -1;
+  if ((double)(tile + 2 * apron) * (double)scale > 4096.0) return -1;
+  const int tiles = (out_size + tile - 1) / tile;
+  int best = 0;
+  for (int t = 0; t < tiles; ++t) {
+    const int o0 = std::max(t * tile - apron, 0);
+    const int ol = std::min(t * tile + tile - 1 + apron, out_size - 1);
+    const float p0 = (float)o0 * scale, pl = (float)ol * scale;  // two roundings each, as on the device
+    const int f0 = (int)std::floor(p0 + bias), fl = (int)std::floor(pl + bias);
+    best = std::max(best, fl - f0 + 4);
+  }
+  return best;
 }
 
 static const uint32_t kKnownFlags = FSR1_FLAG_HDR_SQUARE | FSR1_FLAG_RCAS_DENOISE | FSR1_FLAG_RCAS_PASSTHROUGH_ALPHA |
@@ -125,11 +138,13 @@ int fsr1_easu_dispatch(const fsr1_image* in, const fsr1_image* out, const uint32
   if (in->frames != out->frames) return fail(FSR1_ERR_INVALID_ARGUMENT, "easu: frame counts differ (%d vs %d)", in->frames, out->frames);
   if (overlaps(in, a.in, out, a.out)) return fail(FSR1_ERR_INVALID_ARGUMENT, "easu: input and output overlap");
   memcpy(a.con, con, sizeof a.con);
-  float sx, sy;
+  float sx, sy, bx, by;
   memcpy(&sx, &con[0], 4);
   memcpy(&sy, &con[1], 4);
-  a.fp_w = footprint_cap(kTileW, sx);
-  a.fp_h = footprint_cap(kTileH, sy);
+  memcpy(&bx, &con[2], 4);
+  memcpy(&by, &con[3], 4);
+  a.fp_w = footprint_extent(out->width, kTileW, 0, sx, bx);
+  a.fp_h = footprint_extent(out->height, kTileH, 0, sy, by);
   if (a.fp_w < 0 || a.fp_h < 0) return fail(FSR1_ERR_INVALID_ARGUMENT, "easu: scale constants con0.xy = (%g, %g) are not usable", sx, sy);
   if (easu_lds_bytes(in->format, a.fp_w, a.fp_h) > 160 * 1024)
     return fail(FSR1_ERR_UNSUPPORTED, "easu: input/output ratio (%g, %g) needs a %dx%d texel footprint per tile, beyond the LDS budget "
@@ -190,11 +205,13 @@ int fsr1_easu_rcas_fused_dispatch(const fsr1_image* in, const fsr1_image* out, c
   if (flags & FSR1_FLAG_MATH_PACKED_FP16) return fail(FSR1_ERR_UNSUPPORTED, "fused: packed-fp16 math is not available in the fused kernel");
   memcpy(a.easu_con, easu_con, sizeof a.easu_con);
   memcpy(a.rcas_con, rcas_con, sizeof a.rcas_con);
-  float sx, sy;
+  float sx, sy, bx, by;
   memcpy(&sx, &easu_con[0], 4);
   memcpy(&sy, &easu_con[1], 4);
-  a.fp_w = footprint_cap(kTileW + 2, sx);
-  a.fp_h = footprint_cap(kFusedTileH + 2, sy);
+  memcpy(&bx, &easu_con[2], 4);
+  memcpy(&by, &easu_con[3], 4);
+  a.fp_w = footprint_extent(out->width, kTileW, 1, sx, bx);
+  a.fp_h = footprint_extent(out->height, kFusedTileH, 1, sy, by);
   if (a.fp_w < 0 || a.fp_h < 0) return fail(FSR1_ERR_INVALID_ARGUMENT, "fused: scale constants con0.xy = (%g, %g) are not usable", sx, sy);
   if (fused_lds_bytes(in->format, a.fp_w, a.fp_h) > 160 * 1024)
     return fail(FSR1_ERR_UNSUPPORTED, "fused: input/output ratio (%g, %g) needs more LDS than a CU has", sx, sy);
