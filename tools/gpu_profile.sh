@@ -9,11 +9,11 @@ mkdir -p "$OUT"
 export TMPDIR=/tmp
 BENCH="python $PWD/bench.py --no-cpu-baseline $*"
 cd /tmp
-rocprofv3 --kernel-trace --stats -d "$OUT/stats" -o r -- $BENCH --steps 200 --warmup 20 > "$OUT/stats.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o r -- $BENCH --steps 400 --warmup 50 > "$OUT/stats.log" 2>&1
 for pass in "fetch:FETCH_SIZE" "write:WRITE_SIZE" "tcc:TCC_HIT_sum TCC_MISS_sum" \
             "sq1:SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VMEM_RD" \
             "sq2:SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_WR"; do
   name=${pass%%:*}; ctrs=${pass#*:}
-  rocprofv3 --kernel-trace --pmc $ctrs -d "$OUT/$name" -o r -- $BENCH --steps 20 --warmup 4 > "$OUT/$name.log" 2>&1
+  rocprofv3 --kernel-trace --output-format csv --pmc $ctrs -d "$OUT/$name" -o r -- $BENCH --steps 20 --warmup 4 > "$OUT/$name.log" 2>&1
 done
 grep -h '^{' "$OUT/stats.log" | tail -1
