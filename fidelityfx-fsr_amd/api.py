@@ -16,6 +16,8 @@ from ._lib import Fsr1Error, fsr1_image, fsr1_params  # noqa: F401
 
 FORMAT_RGBA16F = 0
 FORMAT_RGBA32F = 1
+FORMAT_RGBA8_UNORM = 2
+FORMAT_R10G10B10A2_UNORM = 3
 
 FLAG_HDR_SQUARE = 1 << 0
 FLAG_RCAS_DENOISE = 1 << 1
@@ -68,11 +70,23 @@ def AU1_AH1_AF1(f):
 # images
 # --------------------------------------------------------------------------------------------------
 def image_of(t):
-    """fsr1_image descriptor of a CUDA torch tensor shaped (H,W,4) or (N,H,W,4), float16/float32.
-    Row and frame strides are honoured; the innermost (x, channel) dims must be dense."""
+    """fsr1_image descriptor of a CUDA torch tensor:
+      float16 / float32 / uint8, shaped (H,W,4) or (N,H,W,4)  -> RGBA16F / RGBA32F / RGBA8_UNORM
+      int32, shaped (H,W) or (N,H,W)                          -> R10G10B10A2_UNORM (one packed word per pixel)
+    Row and frame strides are honoured; the innermost (x[, channel]) dims must be dense."""
     import torch
     if not t.is_cuda:
         raise Fsr1Error("image tensors must live on the GPU (got %s); there is no CPU path" % t.device)
+    if t.dtype == torch.int32:
+        if t.dim() == 2:
+            t = t.unsqueeze(0)
+        if t.dim() != 3:
+            raise Fsr1Error("expected (N,H,W) packed R10G10B10A2 words, got %s" % (tuple(t.shape),))
+        n, h, w = t.shape
+        sn, sh, sw = t.stride()
+        if sw != 1:
+            raise Fsr1Error("pixels must be dense along x")
+        return fsr1_image(t.data_ptr(), w, h, FORMAT_R10G10B10A2_UNORM, n, sh * 4, sn * 4 if n > 1 else 0)
     if t.dim() == 3:
         t = t.unsqueeze(0)
     if t.dim() != 4 or t.shape[-1] != 4:
@@ -81,6 +95,8 @@ def image_of(t):
         fmt, es = FORMAT_RGBA16F, 2
     elif t.dtype == torch.float32:
         fmt, es = FORMAT_RGBA32F, 4
+    elif t.dtype == torch.uint8:
+        fmt, es = FORMAT_RGBA8_UNORM, 1
     else:
         raise Fsr1Error("unsupported dtype %s" % t.dtype)
     n, h, w, _ = t.shape

@@ -49,14 +49,14 @@ static int hip_fail(hipError_t e, const char* what) {
   return fail(FSR1_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
 }
 
-static size_t pixel_bytes(int fmt) { return fmt == FSR1_FORMAT_RGBA16F ? 8 : 16; }
+static size_t pixel_bytes(int fmt) { return fmt == FSR1_FORMAT_RGBA32F ? 16 : (fmt == FSR1_FORMAT_RGBA16F ? 8 : 4); }
 
 static int check_image(const fsr1_image* im, const char* name, ImageView* v) {
   if (!im) return fail(FSR1_ERR_INVALID_ARGUMENT, "%s: null image descriptor", name);
   if (!im->data) return fail(FSR1_ERR_INVALID_ARGUMENT, "%s: null data pointer", name);
   if (im->width <= 0 || im->height <= 0 || im->frames <= 0)
     return fail(FSR1_ERR_INVALID_ARGUMENT, "%s: bad extent %dx%dx%d", name, im->width, im->height, im->frames);
-  if (im->format != FSR1_FORMAT_RGBA16F && im->format != FSR1_FORMAT_RGBA32F)
+  if (im->format < FSR1_FORMAT_RGBA16F || im->format > FSR1_FORMAT_R10G10B10A2_UNORM)
     return fail(FSR1_ERR_UNSUPPORTED, "%s: unsupported format %d", name, im->format);
   const size_t px = pixel_bytes(im->format);
   const long long pitch = im->row_pitch_bytes ? im->row_pitch_bytes : (long long)im->width * (long long)px;

@@ -113,6 +113,40 @@ template <> struct Pixel<FSR1_FORMAT_RGBA16F> {
   static __device__ __forceinline__ T store(float r, float g, float b, float a) { return T{to_half(r), to_half(g), to_half(b), to_half(a)}; }
   static __device__ __forceinline__ T zero() { return T{(half_t)0, (half_t)0, (half_t)0, (half_t)0}; }
 };
+// UNORM decode: code / N correctly rounded (N = 255, 1023, 3) without a division: the product by the rounded
+// reciprocal is within 1 ulp, one Newton residual step lands on the correctly rounded quotient (checked
+// exhaustively for every code).  Encode: (uint) fma(clamp(x,0,1), N, 0.5), truncating; NaN -> 0.
+template <int N>
+__device__ __forceinline__ float unorm_decode(uint32_t code) {
+  const float c = (float)code;
+  const float r = 1.0f / (float)N;  // compile-time constant
+  const float q = c * r;
+  return fmaf(fmaf(-q, (float)N, c), r, q);
+}
+template <int N>
+__device__ __forceinline__ uint32_t unorm_encode(float x) {
+  return (uint32_t)fmaf(fminf(fmaxf(x, 0.0f), 1.0f), (float)N, 0.5f);
+}
+template <> struct Pixel<FSR1_FORMAT_RGBA8_UNORM> {
+  typedef uint32_t T;
+  static __device__ __forceinline__ float4_t load(const T& p) {
+    return float4_t{unorm_decode<255>(p & 0xffu), unorm_decode<255>((p >> 8) & 0xffu), unorm_decode<255>((p >> 16) & 0xffu), unorm_decode<255>(p >> 24)};
+  }
+  static __device__ __forceinline__ T store(float r, float g, float b, float a) {
+    return unorm_encode<255>(r) | (unorm_encode<255>(g) << 8) | (unorm_encode<255>(b) << 16) | (unorm_encode<255>(a) << 24);
+  }
+  static __device__ __forceinline__ T zero() { return 0u; }
+};
+template <> struct Pixel<FSR1_FORMAT_R10G10B10A2_UNORM> {
+  typedef uint32_t T;
+  static __device__ __forceinline__ float4_t load(const T& p) {
+    return float4_t{unorm_decode<1023>(p & 0x3ffu), unorm_decode<1023>((p >> 10) & 0x3ffu), unorm_decode<1023>((p >> 20) & 0x3ffu), unorm_decode<3>(p >> 30)};
+  }
+  static __device__ __forceinline__ T store(float r, float g, float b, float a) {
+    return unorm_encode<1023>(r) | (unorm_encode<1023>(g) << 10) | (unorm_encode<1023>(b) << 20) | (unorm_encode<3>(a) << 30);
+  }
+  static __device__ __forceinline__ T zero() { return 0u; }
+};
 template <> struct Pixel<FSR1_FORMAT_RGBA32F> {
   typedef float4_t T;
   static __device__ __forceinline__ float4_t load(const T& p) { return p; }

@@ -99,8 +99,15 @@ hipError_t easu_launch(const EasuArgs& a, int fmt, bool exact, hipStream_t strea
     }                                                                                                   \
     hipLaunchKernelGGL((easu_kernel<F, E>), grid, block, lds, stream, a);                               \
   } while (0)
-  if (fmt == FSR1_FORMAT_RGBA16F) { if (exact) FSR1_LAUNCH(FSR1_FORMAT_RGBA16F, true); else FSR1_LAUNCH(FSR1_FORMAT_RGBA16F, false); }
-  else { if (exact) FSR1_LAUNCH(FSR1_FORMAT_RGBA32F, true); else FSR1_LAUNCH(FSR1_FORMAT_RGBA32F, false); }
+#define FSR1_LAUNCH_E(F) do { if (exact) FSR1_LAUNCH(F, true); else FSR1_LAUNCH(F, false); } while (0)
+  switch (fmt) {
+    case FSR1_FORMAT_RGBA16F: FSR1_LAUNCH_E(FSR1_FORMAT_RGBA16F); break;
+    case FSR1_FORMAT_RGBA32F: FSR1_LAUNCH_E(FSR1_FORMAT_RGBA32F); break;
+    case FSR1_FORMAT_RGBA8_UNORM: FSR1_LAUNCH_E(FSR1_FORMAT_RGBA8_UNORM); break;
+    case FSR1_FORMAT_R10G10B10A2_UNORM: FSR1_LAUNCH_E(FSR1_FORMAT_R10G10B10A2_UNORM); break;
+    default: return hipErrorInvalidValue;
+  }
+#undef FSR1_LAUNCH_E
 #undef FSR1_LAUNCH
   return hipGetLastError();
 }

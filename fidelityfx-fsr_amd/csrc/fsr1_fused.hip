@@ -89,7 +89,7 @@ __global__ void __launch_bounds__(kThreads) fused_kernel(const FusedArgs a) {
 }
 
 size_t fused_lds_bytes(int fmt, int fp_w, int fp_h) {
-  const size_t texel = fmt == FSR1_FORMAT_RGBA16F ? 8 : 16;
+  const size_t texel = fmt == FSR1_FORMAT_RGBA32F ? 16 : (fmt == FSR1_FORMAT_RGBA16F ? 8 : 4);
   return (size_t)fp_w * fp_h * kEasuLdsPerTexel + (size_t)kMidW * kMidH * texel;
 }
 
@@ -105,8 +105,15 @@ hipError_t fused_launch(const FusedArgs& a, int fmt, bool exact, hipStream_t str
     }                                                                                                   \
     hipLaunchKernelGGL((fused_kernel<F, E>), grid, block, lds, stream, a);                              \
   } while (0)
-  if (fmt == FSR1_FORMAT_RGBA16F) { if (exact) FSR1_LAUNCH(FSR1_FORMAT_RGBA16F, true); else FSR1_LAUNCH(FSR1_FORMAT_RGBA16F, false); }
-  else { if (exact) FSR1_LAUNCH(FSR1_FORMAT_RGBA32F, true); else FSR1_LAUNCH(FSR1_FORMAT_RGBA32F, false); }
+#define FSR1_LAUNCH_E(F) do { if (exact) FSR1_LAUNCH(F, true); else FSR1_LAUNCH(F, false); } while (0)
+  switch (fmt) {
+    case FSR1_FORMAT_RGBA16F: FSR1_LAUNCH_E(FSR1_FORMAT_RGBA16F); break;
+    case FSR1_FORMAT_RGBA32F: FSR1_LAUNCH_E(FSR1_FORMAT_RGBA32F); break;
+    case FSR1_FORMAT_RGBA8_UNORM: FSR1_LAUNCH_E(FSR1_FORMAT_RGBA8_UNORM); break;
+    case FSR1_FORMAT_R10G10B10A2_UNORM: FSR1_LAUNCH_E(FSR1_FORMAT_R10G10B10A2_UNORM); break;
+    default: return hipErrorInvalidValue;
+  }
+#undef FSR1_LAUNCH_E
 #undef FSR1_LAUNCH
   return hipGetLastError();
 }

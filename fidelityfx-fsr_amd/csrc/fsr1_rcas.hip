@@ -46,6 +46,8 @@ __device__ __forceinline__ rgb_t neighbour(rgb_t keep, rgb_t v) {
 template <int FMT> struct RcasPair;  // two adjacent texels, loaded / stored as one access (8-byte aligned)
 template <> struct RcasPair<FSR1_FORMAT_RGBA16F> { typedef half_t T __attribute__((ext_vector_type(8), aligned(8))); };
 template <> struct RcasPair<FSR1_FORMAT_RGBA32F> { typedef float T __attribute__((ext_vector_type(8), aligned(16))); };
+template <> struct RcasPair<FSR1_FORMAT_RGBA8_UNORM> { typedef uint32_t T __attribute__((ext_vector_type(2), aligned(4))); };
+template <> struct RcasPair<FSR1_FORMAT_R10G10B10A2_UNORM> { typedef uint32_t T __attribute__((ext_vector_type(2), aligned(4))); };
 
 // One 128-column x a.rows strip.  INTERIOR: every texel the strip reads (aprons included) lies inside the
 // image, so nothing is predicated except the apron load of lanes 0 / 63.
@@ -98,7 +100,7 @@ __device__ __forceinline__ void rcas_strip(const RcasArgs& a, int frame, int x0,
   // Ring of raw rows in registers: slot k holds row y0 + r with r % kRing == k; loads run kAhead = kRing - 1 rows
   // ahead of the arithmetic.  The row loop is unrolled by kRing, so every ring index is static, and rolled
   // beyond that so the body stays inside the instruction cache.
-  constexpr int kRing = FMT == FSR1_FORMAT_RGBA16F ? kRcasRing : 4, kAhead = kRing - 1;  // both divide 8
+  constexpr int kRing = FMT == FSR1_FORMAT_RGBA32F ? 4 : kRcasRing, kAhead = kRing - 1;  // both divide 8
   row_t q[kRing];
   rgb_t prev0, prev1, cur0, cur1;
   {
@@ -192,8 +194,15 @@ hipError_t rcas_launch(const RcasArgs& a, int fmt, bool exact, hipStream_t strea
   const bool opts = (a.flags & (FSR1_FLAG_RCAS_DENOISE | FSR1_FLAG_RCAS_PASSTHROUGH_ALPHA | FSR1_FLAG_HDR_SQUARE)) != 0;
 #define FSR1_RCAS(F, E, O) hipLaunchKernelGGL((rcas_kernel<F, E, O>), grid, block, 0, stream, a)
 #define FSR1_RCAS_O(F, E) do { if (opts) FSR1_RCAS(F, E, true); else FSR1_RCAS(F, E, false); } while (0)
-  if (fmt == FSR1_FORMAT_RGBA16F) { if (exact) FSR1_RCAS_O(FSR1_FORMAT_RGBA16F, true); else FSR1_RCAS_O(FSR1_FORMAT_RGBA16F, false); }
-  else { if (exact) FSR1_RCAS_O(FSR1_FORMAT_RGBA32F, true); else FSR1_RCAS_O(FSR1_FORMAT_RGBA32F, false); }
+#define FSR1_RCAS_E(F) do { if (exact) FSR1_RCAS_O(F, true); else FSR1_RCAS_O(F, false); } while (0)
+  switch (fmt) {
+    case FSR1_FORMAT_RGBA16F: FSR1_RCAS_E(FSR1_FORMAT_RGBA16F); break;
+    case FSR1_FORMAT_RGBA32F: FSR1_RCAS_E(FSR1_FORMAT_RGBA32F); break;
+    case FSR1_FORMAT_RGBA8_UNORM: FSR1_RCAS_E(FSR1_FORMAT_RGBA8_UNORM); break;
+    case FSR1_FORMAT_R10G10B10A2_UNORM: FSR1_RCAS_E(FSR1_FORMAT_R10G10B10A2_UNORM); break;
+    default: return hipErrorInvalidValue;
+  }
+#undef FSR1_RCAS_E
 #undef FSR1_RCAS_O
 #undef FSR1_RCAS
   return hipGetLastError();

@@ -55,7 +55,15 @@ uint32_t AU1_AH1_AF1(float f);
 typedef enum fsr1_format {
   FSR1_FORMAT_RGBA16F = 0, /* 8 B/pixel; the view type the reference shader declares
                               (Texture2D<AH4> / RWTexture2D<AH4>, FSR_Pass.hlsl:51-52) */
-  FSR1_FORMAT_RGBA32F = 1  /* 16 B/pixel; the SAMPLE_SLOW_FALLBACK view (FSR_Pass.hlsl:34-36) */
+  FSR1_FORMAT_RGBA32F = 1, /* 16 B/pixel; the SAMPLE_SLOW_FALLBACK view (FSR_Pass.hlsl:34-36) */
+  /* 32 bpp formats — what the sample actually renders into and presents ("use 32bpp formats", ffx_fsr1.h:91;
+   * DXGI_FORMAT_R8G8B8A8_UNORM / R10G10B10A2_UNORM swap chains, SampleRenderer.cpp:193).  The texture unit's
+   * conversions, which the reference leaves to the API, are pinned here to the D3D11 functional-spec rules:
+   *   load  : code / (2^n - 1), correctly rounded to binary32
+   *   store : (uint) fma(clamp(x, 0, 1), 2^n - 1, 0.5) — one rounding, then truncation; NaN stores 0
+   * Arithmetic between load and store is the F (binary32) path. */
+  FSR1_FORMAT_RGBA8_UNORM = 2,        /* 4 B/pixel: R bits 0-7, G 8-15, B 16-23, A 24-31 */
+  FSR1_FORMAT_R10G10B10A2_UNORM = 3   /* 4 B/pixel: R bits 0-9, G 10-19, B 20-29, A 30-31 */
 } fsr1_format;
 
 typedef struct fsr1_image {
