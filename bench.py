@@ -113,6 +113,8 @@ def main():
     ap.add_argument("--workload", default="1080p_to_4k", choices=sorted(WORKLOADS))
     ap.add_argument("--pipeline", default="two-pass", choices=["two-pass", "fused", "easu"])
     ap.add_argument("--math", default="f", choices=["f", "exact", "h"], help="f: fp32 math (default); exact: reference op order; h: packed fp16")
+    ap.add_argument("--storage", default="rgba16f", choices=["rgba16f", "rgba8"],
+                    help="image format in HBM: rgba16f (BASELINE's 8 B/pixel) or rgba8 (UNORM, 4 B/pixel; SURVEY 8f-N2)")
     ap.add_argument("--ring", type=int, default=0, help="distinct frame sets to rotate over (0 = enough to exceed 256 MiB)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -141,19 +143,28 @@ def main():
 
     in_w, in_h, out_w, out_h, frames = WORKLOADS[args.workload]
     math_flags = {"f": 0, "exact": fsr.FLAG_MATH_EXACT, "h": fsr.FLAG_MATH_PACKED_FP16}[args.math]
-    px = 8  # RGBA16F
+    px = 8 if args.storage == "rgba16f" else 4
+    tdtype = torch.float16 if args.storage == "rgba16f" else torch.uint8
+    if args.storage != "rgba16f" and args.math == "h":
+        raise SystemExit("--math h (FsrEasuH/FsrRcasH) is defined on RGBA16F images")
     in_bytes, out_bytes = in_w * in_h * px * frames, out_w * out_h * px * frames
     set_bytes = in_bytes + out_bytes * (2 if args.pipeline == "two-pass" else 1)
     ring = args.ring or max(2, -(-320 * 2**20 // set_bytes))
 
     # synthetic frames: a few distinct numpy frames uploaded once, then varied on-device per ring slot
-    base = [torch.from_numpy(fsr.frames.synthetic_frame(in_w, in_h, k=k + 16 * rank)).to(device) for k in range(min(frames, 2))]
+    def upload(k):
+        f = fsr.frames.synthetic_frame(in_w, in_h, k=k + 16 * rank)
+        if args.storage == "rgba8":
+            f = np.floor(np.clip(f.astype(np.float32), 0.0, 1.0) * 255.0 + 0.5).astype(np.uint8)
+        return torch.from_numpy(f).to(device)
+
+    base = [upload(k) for k in range(min(frames, 2))]
     srcs, mids, dsts = [], [], []
     for s in range(ring):
         t = torch.stack([torch.roll(base[f % len(base)], shifts=(3 * s + f, 5 * s + 2 * f), dims=(0, 1)) for f in range(frames)])
         srcs.append(t.contiguous())
-        mids.append(torch.empty(frames, out_h, out_w, 4, dtype=torch.float16, device=device) if args.pipeline == "two-pass" else None)
-        dsts.append(torch.empty(frames, out_h, out_w, 4, dtype=torch.float16, device=device))
+        mids.append(torch.empty(frames, out_h, out_w, 4, dtype=tdtype, device=device) if args.pipeline == "two-pass" else None)
+        dsts.append(torch.empty(frames, out_h, out_w, 4, dtype=tdtype, device=device))
     easu_con = fsr.FsrEasuCon(in_w, in_h, in_w, in_h, out_w, out_h)
     rcas_con = fsr.FsrRcasCon(0.25)  # sample default attenuation (SampleRenderer.h:49)
 
@@ -224,7 +235,7 @@ def main():
 
     def roof(name):
         gbps = alg[name] / (kern[name] * 1e-3) / 1e9
-        pmc = pmc_traffic(args.workload, args.pipeline, name) if args.math == "f" else None
+        pmc = pmc_traffic(args.workload, args.pipeline, name) if args.math == "f" and args.storage == "rgba16f" else None
         return {"kernel": name, "bound": "hbm", "achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(gbps / HBM_PEAK_GBPS, 4), "traffic": pmc[0] if pmc else None,
                 "traffic_source": pmc[1] if pmc else None, "algorithmic_bytes": alg[name],
@@ -236,9 +247,9 @@ def main():
             "value": round(value, 1), "unit": "Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(total["seconds"] * 1e3 / args.steps, 5), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32" if args.math != "h" else "f16", "data": "synthetic",
-            "config": {"workload": "%s: %dx%d -> %dx%d RGBA16F, %d frame(s)/step/GPU, %s, math=%s, ring of %d frame sets"
-                                   % (args.workload, in_w, in_h, out_w, out_h, frames, args.pipeline, args.math, ring),
-                       "pipeline": args.pipeline, "storage": "rgba16f", "rcas_sharpness_stops": 0.25,
+            "config": {"workload": "%s: %dx%d -> %dx%d %s, %d frame(s)/step/GPU, %s, math=%s, ring of %d frame sets"
+                                   % (args.workload, in_w, in_h, out_w, out_h, args.storage.upper(), frames, args.pipeline, args.math, ring),
+                       "pipeline": args.pipeline, "storage": args.storage, "rcas_sharpness_stops": 0.25,
                        "parallelism": "independent frames per GPU, counters-only collective"},
             "roofline": roof(dominant),
             "kernels": {k: roof(k) for k in kern},
