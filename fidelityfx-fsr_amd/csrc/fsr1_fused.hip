@@ -50,41 +50,76 @@ __global__ void __launch_bounds__(kThreads) fused_kernel(const FusedArgs a) {
   easu_stage_footprint<FMT>(l, a.in, a.in.base + (long long)frame * a.in.frame_stride, fx0, fy0, fw, fh, tid);
 
   // ---- phase 3: EASU on the apron tile -> LDS, in the storage format (EASU runs with Sample.x = 0 when
-  //      RCAS follows: FSR_Filter.cpp:107) ----
-  for (int i = tid; i < kMidW * kMidH; i += kThreads) {
-    const int my = i / kMidW, mx = i - my * kMidW;
-    const int ox = ox0 - 1 + mx, oy = oy0 - 1 + my;
+  //      RCAS follows: FSR_Filter.cpp:107).  A lane owns apron column `lane` (its x position math is done once),
+  //      the waves share the kMidH rows; the two columns left over (64, 65) are one extra partial pass. ----
+  const int lane = tid & 63, wave = tid >> 6;
+  auto easu_to_mid = [&](int mx, int my, float ppx, int lxf, bool x_ok) {
+    const int oy = oy0 - 1 + my;
     texel_t px = Pixel<FMT>::zero();
-    if (ox >= 0 && ox < W && oy >= 0 && oy < H) {
-      float ppx = (float)ox * c0x + c0z, ppy = (float)oy * c0y + c0w;  // :324-326
-      const float fpx = floorf(ppx), fpy = floorf(ppy);
-      ppx -= fpx;
+    if (x_ok && oy >= 0 && oy < H) {
+      float ppy = (float)oy * c0y + c0w;  // :324-326
+      const float fpy = floorf(ppy);
       ppy -= fpy;
-      const int f_idx = ((int)fpy - fy0) * fw + ((int)fpx - fx0);
+      const int f_idx = ((int)fpy - fy0) * fw + lxf;
       px = easu_resolve<FMT, EXACT>(l, f_idx, easu_pixel<EXACT>(l, f_idx, ppx, ppy), false);
     }
-    mid[i] = px;
+    mid[my * kMidW + mx] = px;
+  };
+  auto x_position = [&](int mx, float& ppx, int& lxf) {
+    const int ox = ox0 - 1 + mx;
+    ppx = (float)ox * c0x + c0z;
+    const float fpx = floorf(ppx);
+    ppx -= fpx;
+    lxf = (int)fpx - fx0;
+    return ox >= 0 && ox < W;
+  };
+  {
+    float ppx;
+    int lxf;
+    const bool x_ok = x_position(lane, ppx, lxf);
+#pragma unroll 1
+    for (int my = wave; my < kMidH; my += 4) easu_to_mid(lane, my, ppx, lxf, x_ok);
+  }
+  // leftover columns: 2 x kMidH pixels, given to the last wave (it has the fewest rows above when kMidH % 4 == 2)
+  if (wave == 3) {
+    for (int t = lane; t < 2 * kMidH; t += 64) {
+      float ppx;
+      int lxf;
+      const int mx = kTileW + (t & 1), my = t >> 1;
+      const bool x_ok = x_position(mx, ppx, lxf);
+      easu_to_mid(mx, my, ppx, lxf, x_ok);
+    }
   }
   __syncthreads();
 
-  // ---- phase 4: RCAS from the LDS tile ----
-  const int lane = tid & 63, wave = tid >> 6;
+  // ---- phase 4: RCAS from the LDS tile.  Same streaming shape as the stand-alone pass (fsr1_rcas.hip): a wave
+  //      walks down its rows with b/e/h in registers, d and f are the adjacent lanes' centre texels (DPP wave
+  //      shifts), lanes 0 / 63 read the apron column.  Every lane stays active (DPP sources); stores are predicated. ----
   const int ox = ox0 + lane;
-  if (ox >= W) return;
   const float sharp = as_f32(a.rcas_con[0]);
   const uint32_t flags = a.flags;
   char* const out_col = a.out.base + (long long)frame * a.out.frame_stride + (size_t)ox * sizeof(texel_t);
   auto rgb = [](const texel_t& p) { const float4_t c = Pixel<FMT>::load(p); return rgb_t{c.x, c.y, c.z}; };
-#pragma unroll 4
-  for (int r = 0; r < kFusedTileH / 4; ++r) {
-    const int ry = wave * (kFusedTileH / 4) + r;
-    const int oy = oy0 + ry;
-    if (oy >= H) break;
-    const texel_t* const c = mid + (ry + 1) * kMidW + (lane + 1);
-    const texel_t e = c[0];
-    const rgb_t p = rcas_pixel<EXACT>(rgb(c[-kMidW]), rgb(c[-1]), rgb(e), rgb(c[1]), rgb(c[kMidW]), sharp, flags);
-    const float pa = (flags & FSR1_FLAG_RCAS_PASSTHROUGH_ALPHA) ? Pixel<FMT>::load(e).w : 1.0f;
-    *reinterpret_cast<texel_t*>(out_col + (long long)oy * a.out.pitch) = Pixel<FMT>::store(p.r, p.g, p.b, pa);
+  constexpr int kRowsPerWave = kFusedTileH / 4;
+  const int ry0 = wave * kRowsPerWave;
+  const texel_t* c = mid + (ry0 + 1) * kMidW + (lane + 1);  // centre texel of this lane's first row
+  const int hoff = lane == 0 ? -1 : (lane == 63 ? 1 : 0);  // apron column for the wave's edge lanes
+  rgb_t prev = rgb(c[-kMidW]);
+  texel_t e_raw = c[0];
+  rgb_t cur = rgb(e_raw);
+#pragma unroll
+  for (int r = 0; r < kRowsPerWave; ++r, c += kMidW) {
+    const int oy = oy0 + ry0 + r;
+    const texel_t n_raw = c[kMidW];
+    const rgb_t next = rgb(n_raw), hal = rgb(c[hoff]);
+    const rgb_t d = rgb_t{dpp_f32<kDppWaveShr1>(hal.r, cur.r), dpp_f32<kDppWaveShr1>(hal.g, cur.g), dpp_f32<kDppWaveShr1>(hal.b, cur.b)};
+    const rgb_t f = rgb_t{dpp_f32<kDppWaveShl1>(hal.r, cur.r), dpp_f32<kDppWaveShl1>(hal.g, cur.g), dpp_f32<kDppWaveShl1>(hal.b, cur.b)};
+    const rgb_t p = rcas_pixel<EXACT>(prev, d, cur, f, next, sharp, flags);
+    if (ox < W && oy < H) {
+      const float pa = (flags & FSR1_FLAG_RCAS_PASSTHROUGH_ALPHA) ? Pixel<FMT>::load(e_raw).w : 1.0f;
+      *reinterpret_cast<texel_t*>(out_col + (long long)oy * a.out.pitch) = Pixel<FMT>::store(p.r, p.g, p.b, pa);
+    }
+    prev = cur; cur = next; e_raw = n_raw;
   }
 }
 

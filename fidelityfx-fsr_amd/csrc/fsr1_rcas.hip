@@ -30,13 +30,6 @@ constexpr int kRcasWaves = FSR1_RCAS_WAVES;          // waves per workgroup, sid
 constexpr int kRcasThreads = 64 * kRcasWaves;
 constexpr int kRcasCols = kRcasWaveCols * kRcasWaves;  // columns per workgroup
 constexpr int kRcasRing = FSR1_RCAS_RING;            // rows in flight per lane (RGBA16F); strips are a multiple of it tall
-constexpr int kDppWaveShr1 = 0x138;       // lane i <- lane i-1
-constexpr int kDppWaveShl1 = 0x130;       // lane i <- lane i+1
-
-template <int CTRL>
-__device__ __forceinline__ float dpp_f32(float keep, float v) {
-  return as_f32((uint32_t)__builtin_amdgcn_update_dpp((int)as_u32(keep), (int)as_u32(v), CTRL, 0xf, 0xf, false));
-}
 // fp32 texel of the lane to the left / right; `keep` stays where the neighbour lane does not exist
 template <int CTRL>
 __device__ __forceinline__ rgb_t neighbour(rgb_t keep, rgb_t v) {

@@ -7,6 +7,15 @@ namespace fsr1 {
 
 struct rgb_t { float r, g, b; };
 
+// DPP wave shifts (GFX9 encodings): the value of the lane to the left / right; where that lane does not exist
+// (lane 0 for shr, lane 63 for shl) the destination keeps `keep`.
+constexpr int kDppWaveShr1 = 0x138;  // lane i <- lane i-1
+constexpr int kDppWaveShl1 = 0x130;  // lane i <- lane i+1
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float keep, float v) {
+  return as_f32((uint32_t)__builtin_amdgcn_update_dpp((int)as_u32(keep), (int)as_u32(v), CTRL, 0xf, 0xf, false));
+}
+
 // One pixel of FsrRcasF from its 5 taps (b above, d left, e centre, f right, h below).
 template <bool EXACT>
 __device__ __forceinline__ rgb_t rcas_pixel(rgb_t b, rgb_t d, rgb_t e, rgb_t f, rgb_t h, float sharp, uint32_t flags) {  // flags: compile-time 0 in the plain variant
