@@ -22,6 +22,13 @@ _I = ctypes.c_int
 RCAS_DENOISE = 1
 RCAS_ALPHA = 2
 HDR_SQUARE = 4
+# colour stages (same bit values as FSR1_COLOR_* in include/fsr1_hip.h)
+COLOR_SRTM = 1
+COLOR_LFGA = 2
+COLOR_SRTM_INV = 4
+COLOR_TEPD_C8 = 8
+COLOR_TEPD_C10 = 16
+COLOR_DITHER_FROM_NOISE = 32
 
 
 def build(force=False):
@@ -60,6 +67,12 @@ class _Oracle:
             fn = g(prefix + n)
             fn.argtypes = [_FP, _I, _I, _FP, _U32P, _I, _I, _I]
             fn.restype = None
+        fn = g(prefix + "color_f")
+        fn.argtypes = [_FP, _I, _I, _FP, _I, _F, _F, ctypes.c_uint32, _FP, _I, _I, _I, _I, _I, _I, _I]
+        fn.restype = None
+        fn = g(prefix + "tepd_dit_f")
+        fn.argtypes = [ctypes.c_uint32] * 3
+        fn.restype = _F
         self._prefix = prefix
         self.threads = g(prefix + "omp_threads")()
 
@@ -114,6 +127,31 @@ class _Oracle:
 
     def rcas_h(self, img, con4, flags=0, rows=None):
         return self._rcas("rcas_h", img, con4, flags, rows)
+
+
+    # ---- colour stages (LFGA / SRTM / TEPD) -------------------------------------------------
+    def color_f(self, img, stages, amount=0.0, bias=0.0, frame=0, noise=None, noise_offset=(0, 0), rows=None):
+        """Stage chain SRTM -> LFGA -> SRTM_INV -> TEPD on an (H, W, 4) float image; noise is (S, nH, nW, 4) or (nH, nW, 4)."""
+        img = np.ascontiguousarray(img, np.float32)
+        h, w, _ = img.shape
+        y0, y1 = rows if rows is not None else (0, h)
+        out = np.zeros((h, w, 4), np.float32)
+        if noise is not None:
+            noise = np.ascontiguousarray(noise, np.float32)
+            if noise.ndim == 3:
+                noise = noise[None]
+            ns, nh, nw, _ = noise.shape
+            nptr = noise.ctypes.data_as(_FP)
+        else:
+            ns = nh = nw = 1
+            nptr = ctypes.cast(None, _FP)
+        getattr(self.lib, self._prefix + "color_f")(img.ctypes.data_as(_FP), w, h, out.ctypes.data_as(_FP), int(stages),
+                                                    float(amount), float(bias), int(frame), nptr, nw, nh, ns,
+                                                    int(noise_offset[0]), int(noise_offset[1]), y0, y1)
+        return out
+
+    def FsrTepdDitF(self, x, y, f):
+        return float(getattr(self.lib, self._prefix + "tepd_dit_f")(int(x), int(y), int(f)))
 
 
 def port():

@@ -589,3 +589,83 @@ int oracle_omp_threads(void) {
   return 1;
 #endif
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/* colour stages around the filters: LFGA, SRTM, TEPD (ffx_fsr1.h:986-1199), fp32              */
+/* ------------------------------------------------------------------------------------------ */
+enum { ORACLE_COLOR_SRTM = 1, ORACLE_COLOR_LFGA = 2, ORACLE_COLOR_SRTM_INV = 4, ORACLE_COLOR_TEPD_C8 = 8,
+       ORACLE_COLOR_TEPD_C10 = 16, ORACLE_COLOR_DITHER_FROM_NOISE = 32 };
+
+/* ffx_a.h:1499 AGtZeroF1 = ASatF1(m * +INF): 1 for m > 0, 0 for m < 0, and 0 for m == 0 (0*inf = NaN, which
+ * the minNum/maxNum clamp turns into 0). */
+static inline float AGtZeroF1(float m) { return ASatF1(m * INFINITY); }
+
+/* :1042 FsrSrtmF   c *= rcp(max3(c) + 1) */
+static inline void FsrSrtmF(float c[3]) {
+  float r = ARcpF1(AMax3F1(c[0], c[1], c[2]) + 1.0f);
+  c[0] *= r; c[1] *= r; c[2] *= r;
+}
+/* :1044 FsrSrtmInvF   c *= rcp(max(1/32768, 1 - max3(c))) */
+static inline void FsrSrtmInvF(float c[3]) {
+  float r = ARcpF1(fmaxf((float)(1.0 / 32768.0), 1.0f - AMax3F1(c[0], c[1], c[2])));
+  c[0] *= r; c[1] *= r; c[2] *= r;
+}
+/* :1012 FsrLfgaF   c += (t*a) * min(1-c, c) */
+static inline void FsrLfgaF(float c[3], const float t[3], float a) {
+  for (int i = 0; i < 3; ++i) c[i] += (t[i] * a) * fminf(1.0f - c[i], c[i]);
+}
+/* :1082-1091 FsrTepdDitF.  Constant expressions are folded in double and rounded once to float (the pin used
+ * for every literal expression of the header). */
+static inline float FsrTepdDitF(uint32_t px, uint32_t py, uint32_t f) {
+  float x = (float)(px + f);
+  float y = (float)py;
+  float a = (float)((1.0 + (double)sqrtf(5.0f)) / 2.0); /* GLSL sqrt(5.0) is a binary32 sqrt */
+  float b = (float)(1.0 / 3.69);
+  x = x * a + (y * b);
+  return x - floorf(x); /* fract */
+}
+/* :1097-1110 FsrTepdC8F / :1113-1120 FsrTepdC10F, steps = 255 or 1023 */
+static inline void FsrTepdCF(float c[3], float dit, double steps) {
+  const float k = (float)steps, rk = (float)(1.0 / steps);
+  for (int i = 0; i < 3; ++i) {
+    float n = sqrtf(c[i]);
+    n = floorf(n * k) * rk;
+    float a = n * n;
+    float b = n + rk;
+    b = b * b;
+    float r = (c[i] - b) * APrxMedRcpF1(a - b);
+    c[i] = ASatF1(n + AGtZeroF1(dit - r) * rk);
+  }
+}
+
+/* Stage chain on rows [y0,y1); same contract as ref_color_f in oracle/ref_wrap.cpp. */
+void oracle_color_f(const float* in, int W, int H, float* out, int stages, float amount, float bias, uint32_t frame,
+                    const float* noise, int nW, int nH, int nS, int nox, int noy, int y0, int y1) {
+  (void)H;
+#pragma omp parallel for schedule(dynamic, 4)
+  for (int y = y0; y < y1; ++y)
+    for (int x = 0; x < W; ++x) {
+      const float* q = in + ((size_t)y * W + x) * 4;
+      float c[3] = {q[0], q[1], q[2]};
+      float n[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+      if (noise) {
+        const int ny = (int)((((long long)y + noy) % nH + nH) % nH), nx = (int)((((long long)x + nox) % nW + nW) % nW);
+        const float* t = noise + (((size_t)(frame % (uint32_t)nS) * nH + ny) * nW + nx) * 4;
+        n[0] = t[0]; n[1] = t[1]; n[2] = t[2]; n[3] = t[3];
+      }
+      if (stages & ORACLE_COLOR_SRTM) FsrSrtmF(c);
+      if (stages & ORACLE_COLOR_LFGA) {
+        const float t[3] = {n[0] + bias, n[1] + bias, n[2] + bias};
+        FsrLfgaF(c, t, amount);
+      }
+      if (stages & ORACLE_COLOR_SRTM_INV) FsrSrtmInvF(c);
+      if (stages & (ORACLE_COLOR_TEPD_C8 | ORACLE_COLOR_TEPD_C10)) {
+        const float dit = (stages & ORACLE_COLOR_DITHER_FROM_NOISE) ? ASatF1(n[3]) : FsrTepdDitF((uint32_t)x, (uint32_t)y, frame);
+        FsrTepdCF(c, dit, (stages & ORACLE_COLOR_TEPD_C8) ? 255.0 : 1023.0);
+      }
+      float* o = out + ((size_t)y * W + x) * 4;
+      o[0] = c[0]; o[1] = c[1]; o[2] = c[2]; o[3] = q[3];
+    }
+}
+
+float oracle_tepd_dit_f(uint32_t x, uint32_t y, uint32_t f) { return FsrTepdDitF(x, y, f); }

@@ -100,6 +100,9 @@ static inline uvec4 con4(const uint32_t* c) { return uvec4(c[0], c[1], c[2], c[3
 using namespace glsl;
 
 enum { REF_RCAS_DENOISE = 1, REF_RCAS_ALPHA = 2, REF_HDR_SQUARE = 4 };
+// colour stages around the filters (ffx_fsr1.h:986-1199); same bit values as FSR1_COLOR_* in include/fsr1_hip.h
+enum { REF_COLOR_SRTM = 1, REF_COLOR_LFGA = 2, REF_COLOR_SRTM_INV = 4, REF_COLOR_TEPD_C8 = 8, REF_COLOR_TEPD_C10 = 16,
+       REF_COLOR_DITHER_FROM_NOISE = 32 };
 
 extern "C" {
 
@@ -177,6 +180,42 @@ void ref_rcas_h(const float* in, int W, int H, float* out, const uint32_t* con, 
     }
   }
 }
+
+// Colour stages, in this fixed order, on rows [y0,y1) of a W x H RGBA image (alpha passes through):
+//   FsrSrtmF (:1042) -> FsrLfgaF (:1012) -> FsrSrtmInvF (:1044) -> FsrTepdC8F | FsrTepdC10F (:1097, :1113)
+// grain  t = noise[slice][(y+noy) mod nH][(x+nox) mod nW].rgb + bias   ("tiled blue noise", :1000; slice = frame mod nS,
+//                                                                       the sample stacks its slices likewise: FSR_Tonemapping.hlsl:87)
+// dither   = FsrTepdDitF(uvec2(x,y), frame) (:1082), or saturate(noise.a) as in FSR_Tonemapping.hlsl:87.
+// The result is NOT quantised here: the store conversion belongs to the image format.
+void ref_color_f(const float* in, int W, int H, float* out, int stages, float amount, float bias, uint32_t frame,
+                 const float* noise, int nW, int nH, int nS, int nox, int noy, int y0, int y1) {
+#pragma omp parallel for schedule(dynamic, 4)
+  for (int y = y0; y < y1; ++y) {
+    for (int x = 0; x < W; ++x) {
+      const float* q = in + ((size_t)y * W + x) * 4;
+      vec3 c(q[0], q[1], q[2]);
+      vec4 n(0.f, 0.f, 0.f, 0.f);
+      if (noise) {
+        const int ny = (int)((((long long)y + noy) % nH + nH) % nH), nx = (int)((((long long)x + nox) % nW + nW) % nW);
+        const float* t = noise + (((size_t)(frame % (uint32_t)nS) * nH + ny) * nW + nx) * 4;
+        n = vec4(t[0], t[1], t[2], t[3]);
+      }
+      if (stages & REF_COLOR_SRTM) plain::FsrSrtmF(c);
+      if (stages & REF_COLOR_LFGA) plain::FsrLfgaF(c, vec3(n.x + bias, n.y + bias, n.z + bias), amount);
+      if (stages & REF_COLOR_SRTM_INV) plain::FsrSrtmInvF(c);
+      if (stages & (REF_COLOR_TEPD_C8 | REF_COLOR_TEPD_C10)) {
+        const float dit = (stages & REF_COLOR_DITHER_FROM_NOISE) ? plain::ASatF1(n.w)
+                                                                  : plain::FsrTepdDitF(uvec2((uint)x, (uint)y), frame);
+        if (stages & REF_COLOR_TEPD_C8) plain::FsrTepdC8F(c, dit); else plain::FsrTepdC10F(c, dit);
+      }
+      float* o = out + ((size_t)y * W + x) * 4;
+      o[0] = c.x; o[1] = c.y; o[2] = c.z; o[3] = q[3];
+    }
+  }
+}
+
+// FsrTepdDitF alone (:1082-1091), for the known-answer tests.
+float ref_tepd_dit_f(uint32_t x, uint32_t y, uint32_t f) { return plain::FsrTepdDitF(uvec2(x, y), f); }
 
 // The A_GPU build of the constant setup (same source lines as the A_CPU build, ffx_fsr1.h:156-225,
 // 662-672) — exported so the tests can confirm both builds of the reference agree.

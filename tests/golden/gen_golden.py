@@ -42,6 +42,42 @@ HALF_INPUTS = [1.0, 0.870550573, 65504.0, 65520.0, 1e-8, 6e-8, -0.3333, float("i
                6.103515625e-05, 6.0e-05, 5.9604645e-08, 2.9e-08, 1e30, -1e30, 0.5, 0.25, 3.0e-05]
 
 
+# Colour stages (ffx_fsr1.h:986-1199): (stage bits, image key) -> CPU-evaluated reference output.
+COLOR_CASES = [(1, "hdr"), (2, "ldr"), (4, "ldr"), (8, "ldr"), (16, "ldr"), (8 | 32, "ldr"), (16 | 32, "ldr"), (2 | 8, "ldr"),
+               (2 | 4, "ldr"), (1 | 2 | 4, "hdr"), (2 | 16 | 32, "ldr"), (1 | 2 | 8, "hdr")]
+COLOR_PARAMS = dict(amount=0.75, bias=0.0, frame=3, noise_offset=(5, -3))
+
+
+def color_inputs():
+    """Deterministic inputs of the colour-stage fixture: an LDR frame with exact 0 / 1 / grid values, an HDR frame,
+    and a 2-slice 8x8 signed noise tile (rgb = grain in [-0.5, 0.5], a = dither in [0, 1))."""
+    ldr = frames.synthetic_frame(40, 24, k=6, dtype=np.float32)
+    ldr[0, :8, :3] = np.array([0.0, 1.0, 0.5, 1.0 / 255.0, (7.0 / 255.0) ** 2, 0.999, 1e-7, 0.25], np.float32)[:, None]
+    ldr = ldr.astype(np.float16).astype(np.float32)
+    hdr = (frames.synthetic_frame(40, 24, k=9, dtype=np.float32).astype(np.float64) ** 3 * 4000.0).astype(np.float16).astype(np.float32)
+    hdr[..., 3] = 1.0
+    s = np.uint32(12345)
+    vals = np.empty(2 * 8 * 8 * 4, np.float32)
+    for i in range(vals.size):
+        s = np.uint32((int(s) * 1664525 + 1013904223) & 0xFFFFFFFF)
+        vals[i] = (int(s) >> 8) / float(1 << 24)
+    noise = vals.reshape(2, 8, 8, 4)
+    noise[..., :3] -= 0.5
+    noise = noise.astype(np.float16).astype(np.float32)
+    return ldr, hdr, noise
+
+
+def write_color(R):
+    ldr, hdr, noise = color_inputs()
+    out = {"ldr": ldr.astype(np.float16), "hdr": hdr.astype(np.float16), "noise": noise.astype(np.float16)}
+    for st, key in COLOR_CASES:
+        out["out_%d_%s" % (st, key)] = R.color_f({"ldr": ldr, "hdr": hdr}[key], st, noise=noise, **COLOR_PARAMS)
+    out["dit"] = np.array([[R.FsrTepdDitF(x, y, f) for x in (0, 1, 17, 3839, 7679)] for y, f in ((0, 0), (5, 1), (2159, 7), (4319, 1000))],
+                          np.float32)
+    np.savez_compressed(os.path.join(HERE, "color_stages.npz"), **out)
+    print("color_stages written")
+
+
 def main():
     R = cpu_oracle.ref()
     kat = {"easu": [], "easu_offset": [], "rcas": [], "half": []}
@@ -77,6 +113,8 @@ def main():
         out["easu_f_hdr"] = R.easu_f(img, ow, oh, con, 4)
         np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
         print(name, "written")
+
+    write_color(R)
 
     # SURVEY.md Appendix B.2 KAT frame, fp32 in/out, intermediate not rounded
     img = frames.kat_frame_64x36()
