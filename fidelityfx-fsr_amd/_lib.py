@@ -39,6 +39,22 @@ class fsr1_params(ctypes.Structure):
     ]
 
 
+class fsr1_color_stages(ctypes.Structure):
+    """struct fsr1_color_stages of include/fsr1_hip.h."""
+    _fields_ = [
+        ("stages", ctypes.c_uint32),
+        ("grain_amount", ctypes.c_float),
+        ("grain_bias", ctypes.c_float),
+        ("frame", ctypes.c_uint32),
+        ("noise_offset_x", ctypes.c_int32),
+        ("noise_offset_y", ctypes.c_int32),
+        ("noise", ctypes.POINTER(fsr1_image)),
+    ]
+
+
+_IMG = ctypes.POINTER(fsr1_image)
+_STG = ctypes.POINTER(fsr1_color_stages)
+
 # name -> (restype, argtypes); every symbol include/fsr1_hip.h declares
 SYMBOLS = {
     "FsrEasuCon": (None, [_U32P] * 4 + [_F] * 6),
@@ -48,6 +64,10 @@ SYMBOLS = {
     "fsr1_easu_dispatch": (ctypes.c_int, [ctypes.POINTER(fsr1_image)] * 2 + [_U32P, ctypes.c_uint32, ctypes.c_void_p]),
     "fsr1_rcas_dispatch": (ctypes.c_int, [ctypes.POINTER(fsr1_image)] * 2 + [_U32P, ctypes.c_uint32, ctypes.c_void_p]),
     "fsr1_easu_rcas_fused_dispatch": (ctypes.c_int, [ctypes.POINTER(fsr1_image)] * 2 + [_U32P, _U32P, ctypes.c_uint32, ctypes.c_void_p]),
+    "fsr1_color_dispatch": (ctypes.c_int, [_IMG, _IMG, _STG, ctypes.c_uint32, ctypes.c_void_p]),
+    "fsr1_easu_dispatch_ex": (ctypes.c_int, [_IMG, _IMG, _U32P, ctypes.c_uint32, _STG, ctypes.c_void_p]),
+    "fsr1_rcas_dispatch_ex": (ctypes.c_int, [_IMG, _IMG, _U32P, ctypes.c_uint32, _STG, ctypes.c_void_p]),
+    "fsr1_easu_rcas_fused_dispatch_ex": (ctypes.c_int, [_IMG, _IMG, _U32P, _U32P, ctypes.c_uint32, _STG, ctypes.c_void_p]),
     "fsr1_upscale": (ctypes.c_int, [ctypes.POINTER(fsr1_image)] * 3 + [ctypes.POINTER(fsr1_params), ctypes.c_void_p]),
     "fsr1_last_error": (ctypes.c_char_p, []),
     "fsr1_version": (ctypes.c_int, []),

@@ -12,7 +12,7 @@ import ctypes
 import numpy as np
 
 from . import _lib
-from ._lib import Fsr1Error, fsr1_image, fsr1_params  # noqa: F401
+from ._lib import Fsr1Error, fsr1_color_stages, fsr1_image, fsr1_params  # noqa: F401
 
 FORMAT_RGBA16F = 0
 FORMAT_RGBA32F = 1
@@ -24,6 +24,14 @@ FLAG_RCAS_DENOISE = 1 << 1
 FLAG_RCAS_PASSTHROUGH_ALPHA = 1 << 2
 FLAG_MATH_EXACT = 1 << 4
 FLAG_MATH_PACKED_FP16 = 1 << 5
+
+# colour stages (ffx_fsr1.h:986-1199), fixed order SRTM -> LFGA -> SRTM_INV -> TEPD
+COLOR_SRTM = 1 << 0
+COLOR_LFGA = 1 << 1
+COLOR_SRTM_INV = 1 << 2
+COLOR_TEPD_C8 = 1 << 3
+COLOR_TEPD_C10 = 1 << 4
+COLOR_DITHER_FROM_NOISE = 1 << 5
 
 _U32P = ctypes.POINTER(ctypes.c_uint32)
 
@@ -122,33 +130,77 @@ def _con(c, n):
 # --------------------------------------------------------------------------------------------------
 # device passes
 # --------------------------------------------------------------------------------------------------
-def easu(src, dst, con=None, flags=0, stream=None):
-    """dst = EASU(src).  con defaults to FsrEasuCon(viewport = input size)."""
+class ColorStages:
+    """fsr1_color_stages: which of FsrSrtmF / FsrLfgaF / FsrSrtmInvF / FsrTepdC8F|C10F run, and their inputs
+    (ffx_fsr1.h:986-1199).  `noise` is a CUDA tensor (tiled grain / dither texture, (S,h,w,4) or (h,w,4))."""
+
+    def __init__(self, stages, grain_amount=0.0, grain_bias=0.0, frame=0, noise=None, noise_offset=(0, 0)):
+        self.stages, self.grain_amount, self.grain_bias, self.frame = int(stages), float(grain_amount), float(grain_bias), int(frame)
+        self.noise, self.noise_offset = noise, (int(noise_offset[0]), int(noise_offset[1]))
+
+    def c_struct(self):
+        """-> (fsr1_color_stages, keep-alive tuple)"""
+        img = image_of(self.noise) if self.noise is not None else None
+        st = fsr1_color_stages(self.stages, self.grain_amount, self.grain_bias, self.frame & 0xFFFFFFFF, self.noise_offset[0],
+                               self.noise_offset[1], ctypes.pointer(img) if img is not None else None)
+        return st, (img, self.noise)
+
+
+def _stages(stages):
+    if stages is None:
+        return None, None
+    st, keep = stages.c_struct()
+    return ctypes.byref(st), (st, keep)
+
+
+def easu(src, dst, con=None, flags=0, stream=None, stages=None):
+    """dst = EASU(src).  con defaults to FsrEasuCon(viewport = input size).  stages: optional ColorStages fused in."""
     i, o = image_of(src), image_of(dst)
     if con is None:
         con = FsrEasuCon(i.width, i.height, i.width, i.height, o.width, o.height)
     con = _con(con, 16)
-    _lib.check(_lib.load().fsr1_easu_dispatch(ctypes.byref(i), ctypes.byref(o), _u32p(con), flags, _stream_ptr(stream)))
+    if stages is None:
+        _lib.check(_lib.load().fsr1_easu_dispatch(ctypes.byref(i), ctypes.byref(o), _u32p(con), flags, _stream_ptr(stream)))
+    else:
+        sp, _keep = _stages(stages)
+        _lib.check(_lib.load().fsr1_easu_dispatch_ex(ctypes.byref(i), ctypes.byref(o), _u32p(con), flags, sp, _stream_ptr(stream)))
     return dst
 
 
-def rcas(src, dst, con=None, sharpness=0.25, flags=0, stream=None):
-    """dst = RCAS(src); con defaults to FsrRcasCon(sharpness)."""
+def rcas(src, dst, con=None, sharpness=0.25, flags=0, stream=None, stages=None):
+    """dst = RCAS(src); con defaults to FsrRcasCon(sharpness).  stages: optional ColorStages fused in."""
     i, o = image_of(src), image_of(dst)
     con = _con(FsrRcasCon(sharpness) if con is None else con, 4)
-    _lib.check(_lib.load().fsr1_rcas_dispatch(ctypes.byref(i), ctypes.byref(o), _u32p(con), flags, _stream_ptr(stream)))
+    if stages is None:
+        _lib.check(_lib.load().fsr1_rcas_dispatch(ctypes.byref(i), ctypes.byref(o), _u32p(con), flags, _stream_ptr(stream)))
+    else:
+        sp, _keep = _stages(stages)
+        _lib.check(_lib.load().fsr1_rcas_dispatch_ex(ctypes.byref(i), ctypes.byref(o), _u32p(con), flags, sp, _stream_ptr(stream)))
     return dst
 
 
-def easu_rcas_fused(src, dst, easu_con=None, rcas_con=None, sharpness=0.25, flags=0, stream=None):
-    """dst = RCAS(EASU(src)) in one launch (intermediate kept in LDS)."""
+def easu_rcas_fused(src, dst, easu_con=None, rcas_con=None, sharpness=0.25, flags=0, stream=None, stages=None):
+    """dst = RCAS(EASU(src)) in one launch (intermediate kept in LDS).  stages: optional ColorStages fused in."""
     i, o = image_of(src), image_of(dst)
     if easu_con is None:
         easu_con = FsrEasuCon(i.width, i.height, i.width, i.height, o.width, o.height)
     easu_con = _con(easu_con, 16)
     rcas_con = _con(FsrRcasCon(sharpness) if rcas_con is None else rcas_con, 4)
-    _lib.check(_lib.load().fsr1_easu_rcas_fused_dispatch(ctypes.byref(i), ctypes.byref(o), _u32p(easu_con), _u32p(rcas_con),
-                                                         flags, _stream_ptr(stream)))
+    if stages is None:
+        _lib.check(_lib.load().fsr1_easu_rcas_fused_dispatch(ctypes.byref(i), ctypes.byref(o), _u32p(easu_con), _u32p(rcas_con),
+                                                             flags, _stream_ptr(stream)))
+    else:
+        sp, _keep = _stages(stages)
+        _lib.check(_lib.load().fsr1_easu_rcas_fused_dispatch_ex(ctypes.byref(i), ctypes.byref(o), _u32p(easu_con), _u32p(rcas_con),
+                                                                flags, sp, _stream_ptr(stream)))
+    return dst
+
+
+def color(src, dst, stages, flags=0, stream=None):
+    """dst = stages(src): the stand-alone colour pass (FsrSrtmF -> FsrLfgaF -> FsrSrtmInvF -> FsrTepdC8F|C10F)."""
+    i, o = image_of(src), image_of(dst)
+    sp, _keep = _stages(stages)
+    _lib.check(_lib.load().fsr1_color_dispatch(ctypes.byref(i), ctypes.byref(o), sp, flags, _stream_ptr(stream)))
     return dst
 
 

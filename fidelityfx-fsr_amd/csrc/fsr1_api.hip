@@ -18,6 +18,11 @@ void rcas_geometry(int width, int height, int frames, int* tiles_x, int* tiles_y
 hipError_t fused_launch(const FusedArgs& a, int fmt, bool exact, hipStream_t stream);
 size_t fused_lds_bytes(int fmt, int fp_w, int fp_h);
 hipError_t easu_h_launch(const EasuArgs& a, hipStream_t stream);
+hipError_t easu_color_launch(const EasuArgs& a, int fin, int fout, bool exact, hipStream_t stream);
+hipError_t rcas_color_launch(const RcasArgs& a, int fin, int fout, bool exact, hipStream_t stream);
+hipError_t fused_color_launch(const FusedArgs& a, int fin, int fout, bool exact, hipStream_t stream);
+hipError_t color_launch(const ColorPassArgs& a, int fin, int fout, bool exact, hipStream_t stream);
+void color_geometry(int width, int height, int* tiles_x, int* tiles_y);
 hipError_t rcas_h_launch(const RcasArgs& a, hipStream_t stream);
 }  // namespace fsr1
 
@@ -114,6 +119,44 @@ static int check_flags(uint32_t flags) {
   return FSR1_OK;
 }
 
+// fsr1_color_stages -> the device-side ColorArgs; `allowed` = the stage bits this entry point can run.
+// Returns FSR1_OK with c->stages == 0 for a NULL / empty descriptor.
+static const uint32_t kColorStageBits = FSR1_COLOR_SRTM | FSR1_COLOR_LFGA | FSR1_COLOR_SRTM_INV | FSR1_COLOR_TEPD_C8 |
+                                        FSR1_COLOR_TEPD_C10 | FSR1_COLOR_DITHER_FROM_NOISE;
+static int check_color(const fsr1_color_stages* st, const char* who, ColorArgs* c) {
+  memset(c, 0, sizeof *c);
+  if (!st || !st->stages) return FSR1_OK;
+  if (st->stages & ~kColorStageBits) return fail(FSR1_ERR_INVALID_ARGUMENT, "%s: unknown colour stage bits 0x%x", who, st->stages & ~kColorStageBits);
+  if ((st->stages & FSR1_COLOR_TEPD_C8) && (st->stages & FSR1_COLOR_TEPD_C10))
+    return fail(FSR1_ERR_INVALID_ARGUMENT, "%s: FSR1_COLOR_TEPD_C8 and FSR1_COLOR_TEPD_C10 are exclusive", who);
+  if ((st->stages & FSR1_COLOR_DITHER_FROM_NOISE) && !(st->stages & (FSR1_COLOR_TEPD_C8 | FSR1_COLOR_TEPD_C10)))
+    return fail(FSR1_ERR_INVALID_ARGUMENT, "%s: FSR1_COLOR_DITHER_FROM_NOISE needs a TEPD stage", who);
+  c->stages = st->stages;
+  c->amount = st->grain_amount;
+  c->bias = st->grain_bias;
+  c->frame = st->frame;
+  if (st->stages & (FSR1_COLOR_LFGA | FSR1_COLOR_DITHER_FROM_NOISE)) {
+    if (!st->noise) return fail(FSR1_ERR_INVALID_ARGUMENT, "%s: FSR1_COLOR_LFGA / FSR1_COLOR_DITHER_FROM_NOISE need a noise image", who);
+    ImageView nv;
+    int rc = check_image(st->noise, "noise", &nv);
+    if (rc) return rc;
+    const long long slice = (long long)(st->frame % (uint32_t)st->noise->frames);
+    c->noise.base = nv.base + slice * nv.frame_stride;
+    c->noise.width = nv.width;
+    c->noise.height = nv.height;
+    c->noise.pitch = nv.pitch;
+    c->noise.format = st->noise->format;
+    c->noise.off_x = (int)((((long long)st->noise_offset_x % nv.width) + nv.width) % nv.width);
+    c->noise.off_y = (int)((((long long)st->noise_offset_y % nv.height) + nv.height) % nv.height);
+  }
+  return FSR1_OK;
+}
+
+// Format pairs the colour variants of the EASU / RCAS / fused kernels are built for.
+static bool color_format_pair_ok(int fin, int fout) {
+  return fin == fout || (fin == FSR1_FORMAT_RGBA16F && (fout == FSR1_FORMAT_RGBA8_UNORM || fout == FSR1_FORMAT_R10G10B10A2_UNORM));
+}
+
 extern "C" {
 
 const char* fsr1_last_error(void) { return g_err; }
@@ -128,13 +171,21 @@ int fsr1_device_count(void) {
 
 int fsr1_easu_dispatch(const fsr1_image* in, const fsr1_image* out, const uint32_t con[16], uint32_t flags,
                        void* stream) {
+  return fsr1_easu_dispatch_ex(in, out, con, flags, nullptr, stream);
+}
+
+int fsr1_easu_dispatch_ex(const fsr1_image* in, const fsr1_image* out, const uint32_t con[16], uint32_t flags,
+                          const fsr1_color_stages* stages, void* stream) {
   EasuArgs a;
   int rc;
   if ((rc = check_flags(flags))) return rc;
   if ((rc = check_image(in, "easu input", &a.in))) return rc;
   if ((rc = check_image(out, "easu output", &a.out))) return rc;
+  if ((rc = check_color(stages, "easu", &a.color))) return rc;
   if (!con) return fail(FSR1_ERR_INVALID_ARGUMENT, "easu: null constants");
-  if (in->format != out->format) return fail(FSR1_ERR_UNSUPPORTED, "easu: input and output formats differ");
+  if (a.color.stages ? !color_format_pair_ok(in->format, out->format) : in->format != out->format)
+    return fail(FSR1_ERR_UNSUPPORTED, "easu: unsupported input/output format pair %d -> %d", in->format, out->format);
+  if (a.color.stages && (flags & FSR1_FLAG_MATH_PACKED_FP16)) return fail(FSR1_ERR_UNSUPPORTED, "easu: colour stages run with the F (binary32) arithmetic");
   if (in->frames != out->frames) return fail(FSR1_ERR_INVALID_ARGUMENT, "easu: frame counts differ (%d vs %d)", in->frames, out->frames);
   if (overlaps(in, a.in, out, a.out)) return fail(FSR1_ERR_INVALID_ARGUMENT, "easu: input and output overlap");
   memcpy(a.con, con, sizeof a.con);
@@ -157,6 +208,8 @@ int fsr1_easu_dispatch(const fsr1_image* in, const fsr1_image* out, const uint32
   if (flags & FSR1_FLAG_MATH_PACKED_FP16) {
     if (in->format != FSR1_FORMAT_RGBA16F) return fail(FSR1_ERR_UNSUPPORTED, "easu: packed-fp16 math needs RGBA16F images");
     e = easu_h_launch(a, static_cast<hipStream_t>(stream));
+  } else if (a.color.stages) {
+    e = easu_color_launch(a, in->format, out->format, (flags & FSR1_FLAG_MATH_EXACT) != 0, static_cast<hipStream_t>(stream));
   } else {
     e = easu_launch(a, in->format, (flags & FSR1_FLAG_MATH_EXACT) != 0, static_cast<hipStream_t>(stream));
   }
@@ -165,13 +218,21 @@ int fsr1_easu_dispatch(const fsr1_image* in, const fsr1_image* out, const uint32
 }
 
 int fsr1_rcas_dispatch(const fsr1_image* in, const fsr1_image* out, const uint32_t con[4], uint32_t flags, void* stream) {
+  return fsr1_rcas_dispatch_ex(in, out, con, flags, nullptr, stream);
+}
+
+int fsr1_rcas_dispatch_ex(const fsr1_image* in, const fsr1_image* out, const uint32_t con[4], uint32_t flags,
+                          const fsr1_color_stages* stages, void* stream) {
   RcasArgs a;
   int rc;
   if ((rc = check_flags(flags))) return rc;
   if ((rc = check_image(in, "rcas input", &a.in))) return rc;
   if ((rc = check_image(out, "rcas output", &a.out))) return rc;
+  if ((rc = check_color(stages, "rcas", &a.color))) return rc;
   if (!con) return fail(FSR1_ERR_INVALID_ARGUMENT, "rcas: null constants");
-  if (in->format != out->format) return fail(FSR1_ERR_UNSUPPORTED, "rcas: input and output formats differ");
+  if (a.color.stages ? !color_format_pair_ok(in->format, out->format) : in->format != out->format)
+    return fail(FSR1_ERR_UNSUPPORTED, "rcas: unsupported input/output format pair %d -> %d", in->format, out->format);
+  if (a.color.stages && (flags & FSR1_FLAG_MATH_PACKED_FP16)) return fail(FSR1_ERR_UNSUPPORTED, "rcas: colour stages run with the F (binary32) arithmetic");
   if (in->width != out->width || in->height != out->height || in->frames != out->frames)
     return fail(FSR1_ERR_INVALID_ARGUMENT, "rcas: input %dx%dx%d and output %dx%dx%d extents differ", in->width, in->height,
                 in->frames, out->width, out->height, out->frames);
@@ -184,6 +245,8 @@ int fsr1_rcas_dispatch(const fsr1_image* in, const fsr1_image* out, const uint32
   if (flags & FSR1_FLAG_MATH_PACKED_FP16) {
     if (in->format != FSR1_FORMAT_RGBA16F) return fail(FSR1_ERR_UNSUPPORTED, "rcas: packed-fp16 math needs RGBA16F images");
     e = rcas_h_launch(a, static_cast<hipStream_t>(stream));
+  } else if (a.color.stages) {
+    e = rcas_color_launch(a, in->format, out->format, (flags & FSR1_FLAG_MATH_EXACT) != 0, static_cast<hipStream_t>(stream));
   } else {
     e = rcas_launch(a, in->format, (flags & FSR1_FLAG_MATH_EXACT) != 0, static_cast<hipStream_t>(stream));
   }
@@ -193,13 +256,21 @@ int fsr1_rcas_dispatch(const fsr1_image* in, const fsr1_image* out, const uint32
 
 int fsr1_easu_rcas_fused_dispatch(const fsr1_image* in, const fsr1_image* out, const uint32_t easu_con[16],
                                   const uint32_t rcas_con[4], uint32_t flags, void* stream) {
+  return fsr1_easu_rcas_fused_dispatch_ex(in, out, easu_con, rcas_con, flags, nullptr, stream);
+}
+
+int fsr1_easu_rcas_fused_dispatch_ex(const fsr1_image* in, const fsr1_image* out, const uint32_t easu_con[16],
+                                     const uint32_t rcas_con[4], uint32_t flags, const fsr1_color_stages* stages,
+                                     void* stream) {
   FusedArgs a;
   int rc;
   if ((rc = check_flags(flags))) return rc;
   if ((rc = check_image(in, "fused input", &a.in))) return rc;
   if ((rc = check_image(out, "fused output", &a.out))) return rc;
+  if ((rc = check_color(stages, "fused", &a.color))) return rc;
   if (!easu_con || !rcas_con) return fail(FSR1_ERR_INVALID_ARGUMENT, "fused: null constants");
-  if (in->format != out->format) return fail(FSR1_ERR_UNSUPPORTED, "fused: input and output formats differ");
+  if (a.color.stages ? !color_format_pair_ok(in->format, out->format) : in->format != out->format)
+    return fail(FSR1_ERR_UNSUPPORTED, "fused: unsupported input/output format pair %d -> %d", in->format, out->format);
   if (in->frames != out->frames) return fail(FSR1_ERR_INVALID_ARGUMENT, "fused: frame counts differ (%d vs %d)", in->frames, out->frames);
   if (overlaps(in, a.in, out, a.out)) return fail(FSR1_ERR_INVALID_ARGUMENT, "fused: input and output overlap");
   if (flags & FSR1_FLAG_MATH_PACKED_FP16) return fail(FSR1_ERR_UNSUPPORTED, "fused: packed-fp16 math is not available in the fused kernel");
@@ -219,8 +290,32 @@ int fsr1_easu_rcas_fused_dispatch(const fsr1_image* in, const fsr1_image* out, c
   a.tiles_y = (out->height + kFusedTileH - 1) / kFusedTileH;
   a.frames = out->frames;
   a.flags = flags;
-  hipError_t e = fused_launch(a, in->format, (flags & FSR1_FLAG_MATH_EXACT) != 0, static_cast<hipStream_t>(stream));
+  const bool exact = (flags & FSR1_FLAG_MATH_EXACT) != 0;
+  hipError_t e = a.color.stages ? fused_color_launch(a, in->format, out->format, exact, static_cast<hipStream_t>(stream))
+                                : fused_launch(a, in->format, exact, static_cast<hipStream_t>(stream));
   if (e != hipSuccess) return hip_fail(e, "fused launch");
+  return FSR1_OK;
+}
+
+// Stand-alone colour pass (ffx_fsr1.h:986-1199).
+int fsr1_color_dispatch(const fsr1_image* in, const fsr1_image* out, const fsr1_color_stages* stages, uint32_t flags,
+                        void* stream) {
+  ColorPassArgs a;
+  int rc;
+  if (flags & ~(uint32_t)FSR1_FLAG_MATH_EXACT) return fail(FSR1_ERR_INVALID_ARGUMENT, "color: flags may only hold FSR1_FLAG_MATH_EXACT");
+  if ((rc = check_image(in, "color input", &a.in))) return rc;
+  if ((rc = check_image(out, "color output", &a.out))) return rc;
+  if ((rc = check_color(stages, "color", &a.color))) return rc;
+  if (in->width != out->width || in->height != out->height || in->frames != out->frames)
+    return fail(FSR1_ERR_INVALID_ARGUMENT, "color: input %dx%dx%d and output %dx%dx%d extents differ", in->width, in->height,
+                in->frames, out->width, out->height, out->frames);
+  if (overlaps(in, a.in, out, a.out) &&
+      !(in->data == out->data && in->format == out->format && a.in.pitch == a.out.pitch && a.in.frame_stride == a.out.frame_stride))
+    return fail(FSR1_ERR_INVALID_ARGUMENT, "color: input and output overlap without being the same image");
+  color_geometry(out->width, out->height, &a.tiles_x, &a.tiles_y);
+  a.frames = out->frames;
+  hipError_t e = color_launch(a, in->format, out->format, (flags & FSR1_FLAG_MATH_EXACT) != 0, static_cast<hipStream_t>(stream));
+  if (e != hipSuccess) return hip_fail(e, "color launch");
   return FSR1_OK;
 }
 

@@ -36,12 +36,35 @@ struct ImageView {
   long long frame_stride;  // bytes between frames
 };
 
+// Colour stages (fsr1_color_math.h); carried by every argument block, ignored by the plain kernels.
+struct NoiseView {
+  const char* base;  // slice already selected (frame % slices) by the host
+  int width, height;
+  long long pitch;
+  int format;        // fsr1_format
+  int off_x, off_y;  // noise_offset reduced to [0, width) x [0, height) by the host
+};
+
+struct ColorArgs {
+  uint32_t stages;  // FSR1_COLOR_*
+  float amount, bias;
+  uint32_t frame;
+  NoiseView noise;
+};
+
+struct ColorPassArgs {
+  ImageView in, out;
+  int tiles_x, tiles_y, frames;
+  ColorArgs color;
+};
+
 struct EasuArgs {
   ImageView in, out;
   uint32_t con[16];
   int tiles_x, tiles_y, frames;
   int fp_w, fp_h;  // LDS footprint capacity (texels) per tile, >= the largest footprint of any tile
   uint32_t flags;
+  ColorArgs color;
 };
 
 struct RcasArgs {
@@ -50,6 +73,7 @@ struct RcasArgs {
   int tiles_x, tiles_y, frames;
   int rows;  // rows per strip (a multiple of the kernel's row ring), chosen by the launcher
   uint32_t flags;
+  ColorArgs color;
 };
 
 struct FusedArgs {
@@ -59,6 +83,7 @@ struct FusedArgs {
   int tiles_x, tiles_y, frames;
   int fp_w, fp_h;
   uint32_t flags;
+  ColorArgs color;
 };
 
 __device__ __forceinline__ float as_f32(uint32_t u) { return __uint_as_float(u); }

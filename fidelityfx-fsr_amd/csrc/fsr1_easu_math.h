@@ -7,6 +7,7 @@
 // conversions), plain v_fma_f32 everywhere, the window clip done by the free `clamp` modifier
 // instead of v_min_f32, min/max hoisted to the per-texel phase.
 #pragma once
+#include "fsr1_color_math.h"
 #include "fsr1_device.h"
 
 namespace fsr1 {
@@ -33,9 +34,11 @@ __device__ __forceinline__ EasuLds easu_lds_carve(char* smem, int capacity_texel
 // Phases 1 and 2 for the footprint [fx0, fx0+fw) x [fy0, fy0+fh) of input texels (unclamped
 // coordinates; the sampler's clamp-to-edge, FSR_Filter.cpp:48-53, is applied while loading).
 // Ends with a barrier: afterwards every thread may read any footprint entry.
-template <int FMT>
+// PRE: the colour prologue (FsrSrtmF, fsr1_color_math.h) is applied to every texel as it is loaded — the texels in
+// LDS are then arbitrary binary32 values, so the packed binary16 dering bounds are not used (easu_resolve).
+template <int FMT, bool PRE = false, bool EXACT = false>
 __device__ __forceinline__ void easu_stage_footprint(const EasuLds& l, const ImageView& in, const char* in_frame, int fx0, int fy0,
-                                                     int fw, int fh, int tid) {
+                                                     int fw, int fh, int tid, const ColorArgs* color = nullptr) {
   typedef typename Pixel<FMT>::T texel_t;
   const int n = fw * fh;
   const float inv_fw = 1.0f / (float)fw;
@@ -46,7 +49,8 @@ __device__ __forceinline__ void easu_stage_footprint(const EasuLds& l, const Ima
     const int gy = min(max(fy0 + ly, 0), in.height - 1);
     const int gx = min(max(fx0 + lx, 0), in.width - 1);
     const texel_t px = *reinterpret_cast<const texel_t*>(in_frame + (long long)gy * in.pitch + (size_t)gx * sizeof(texel_t));
-    const float4_t c = Pixel<FMT>::load(px);
+    float4_t c = Pixel<FMT>::load(px);
+    if constexpr (PRE) c = color_prologue<EXACT>(*color, c);
     // :363-366  luma*2 = B*0.5 + (R*0.5 + G); the products by 0.5 are exact, so fusing them is too
     l.tex[i] = float4_t{c.x, c.y, c.z, fmaf(c.z, 0.5f, fmaf(c.x, 0.5f, c.y))};
   }
@@ -69,7 +73,7 @@ __device__ __forceinline__ void easu_stage_footprint(const EasuLds& l, const Ima
     lenY = sat(fabsf(dirY) * lenY);
     lenY *= lenY;
     l.ana[i] = float4_t{dirX, dirY, lenX, lenY};
-    if (FMT == FSR1_FORMAT_RGBA16F) {
+    if (FMT == FSR1_FORMAT_RGBA16F && !PRE) {
       // :416-419 min/max over the 2x2 block whose top-left texel is i (f g / j k).  The texels are binary16
       // values, so their min/max are too: keep them packed and clamp after the final rounding (rounding is
       // monotone, the bounds are representable, so both orders give the same binary16).  .w = 1 forces alpha.
@@ -191,10 +195,21 @@ __device__ __forceinline__ rgbf_t easu_pixel(const EasuLds& l, int f_idx, float 
 
 // Dering clamp (:416-419, :437) + alpha = 1 (FSR_Pass.hlsl:80) + optional `c *= c` (FSR_Pass.hlsl:78-79),
 // producing the pixel in its storage format.
-template <int FMT, bool EXACT>
+// Dering clamp in binary32 (:416-419, :437) + optional `c *= c`: the filter's result before the store conversion.
+__device__ __forceinline__ rgbf_t easu_resolve_f(const EasuLds& l, int f_idx, rgbf_t p, bool hdr_square) {
+  const int fw = l.fw;
+  const float4_t cf = l.tex[f_idx], cg = l.tex[f_idx + 1], cj = l.tex[f_idx + fw], ck = l.tex[f_idx + fw + 1];
+  float pr = fminf(fmaxf(max3f(cf.x, cg.x, cj.x), ck.x), fmaxf(fminf(min3f(cf.x, cg.x, cj.x), ck.x), p.r));
+  float pg = fminf(fmaxf(max3f(cf.y, cg.y, cj.y), ck.y), fmaxf(fminf(min3f(cf.y, cg.y, cj.y), ck.y), p.g));
+  float pb = fminf(fmaxf(max3f(cf.z, cg.z, cj.z), ck.z), fmaxf(fminf(min3f(cf.z, cg.z, cj.z), ck.z), p.b));
+  if (hdr_square) { pr *= pr; pg *= pg; pb *= pb; }
+  return rgbf_t{pinned(pr), pinned(pg), pinned(pb)};
+}
+
+template <int FMT, bool EXACT, bool PRE = false>
 __device__ __forceinline__ typename Pixel<FMT>::T easu_resolve(const EasuLds& l, int f_idx, rgbf_t p, bool hdr_square) {
   typedef typename Pixel<FMT>::T texel_t;
-  if constexpr (FMT == FSR1_FORMAT_RGBA16F) if (!hdr_square) {
+  if constexpr (FMT == FSR1_FORMAT_RGBA16F && !PRE) if (!hdr_square) {
     const uint4 mm = l.mm[f_idx];
     half2_t rg = __builtin_convertvector(float2_t{p.r, p.g}, half2_t);  // v_cvt_pk_f16_f32, RTNE
     half2_t b1 = __builtin_convertvector(float2_t{p.b, 1.0f}, half2_t);
@@ -203,14 +218,8 @@ __device__ __forceinline__ typename Pixel<FMT>::T easu_resolve(const EasuLds& l,
     const uint2 packed = {__builtin_bit_cast(uint32_t, rg), __builtin_bit_cast(uint32_t, b1)};
     return __builtin_bit_cast(texel_t, packed);
   }
-  const int fw = l.fw;
-  const float4_t cf = l.tex[f_idx], cg = l.tex[f_idx + 1], cj = l.tex[f_idx + fw], ck = l.tex[f_idx + fw + 1];
-  float pr = fminf(fmaxf(max3f(cf.x, cg.x, cj.x), ck.x), fmaxf(fminf(min3f(cf.x, cg.x, cj.x), ck.x), p.r));
-  float pg = fminf(fmaxf(max3f(cf.y, cg.y, cj.y), ck.y), fmaxf(fminf(min3f(cf.y, cg.y, cj.y), ck.y), p.g));
-  float pb = fminf(fmaxf(max3f(cf.z, cg.z, cj.z), ck.z), fmaxf(fminf(min3f(cf.z, cg.z, cj.z), ck.z), p.b));
-  if (hdr_square) { pr *= pr; pg *= pg; pb *= pb; }
-  pr = pinned(pr); pg = pinned(pg); pb = pinned(pb);
-  return Pixel<FMT>::store(pr, pg, pb, 1.0f);
+  const rgbf_t q = easu_resolve_f(l, f_idx, p, hdr_square);
+  return Pixel<FMT>::store(q.r, q.g, q.b, 1.0f);
 }
 
 }  // namespace fsr1

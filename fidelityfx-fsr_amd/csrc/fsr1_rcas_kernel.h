@@ -1,0 +1,166 @@
+// RCAS kernel template (see fsr1_rcas.hip for the design notes); instantiated by fsr1_rcas.hip (plain pass) and
+// fsr1_rcas_color.hip (colour prologue / epilogue variants).
+#pragma once
+#include "fsr1_color_math.h"
+#include "fsr1_device.h"
+#include "fsr1_rcas_math.h"
+
+namespace fsr1 {
+
+#ifndef FSR1_RCAS_WAVES
+#define FSR1_RCAS_WAVES 2
+#endif
+#ifndef FSR1_RCAS_RING
+#define FSR1_RCAS_RING 8
+#endif
+constexpr int kRcasWaveCols = 128;        // columns per wave (two per lane)
+constexpr int kRcasWaves = FSR1_RCAS_WAVES;          // waves per workgroup, side by side
+constexpr int kRcasThreads = 64 * kRcasWaves;
+constexpr int kRcasCols = kRcasWaveCols * kRcasWaves;  // columns per workgroup
+constexpr int kRcasRing = FSR1_RCAS_RING;            // rows in flight per lane (RGBA16F); strips are a multiple of it tall
+// fp32 texel of the lane to the left / right; `keep` stays where the neighbour lane does not exist
+template <int CTRL>
+__device__ __forceinline__ rgb_t neighbour(rgb_t keep, rgb_t v) {
+  return rgb_t{dpp_f32<CTRL>(keep.r, v.r), dpp_f32<CTRL>(keep.g, v.g), dpp_f32<CTRL>(keep.b, v.b)};
+}
+
+template <int FMT> struct RcasPair;  // two adjacent texels, loaded / stored as one access (8-byte aligned)
+template <> struct RcasPair<FSR1_FORMAT_RGBA16F> { typedef half_t T __attribute__((ext_vector_type(8), aligned(8))); };
+template <> struct RcasPair<FSR1_FORMAT_RGBA32F> { typedef float T __attribute__((ext_vector_type(8), aligned(16))); };
+template <> struct RcasPair<FSR1_FORMAT_RGBA8_UNORM> { typedef uint32_t T __attribute__((ext_vector_type(2), aligned(4))); };
+template <> struct RcasPair<FSR1_FORMAT_R10G10B10A2_UNORM> { typedef uint32_t T __attribute__((ext_vector_type(2), aligned(4))); };
+
+// One 128-column x a.rows strip.  INTERIOR: every texel the strip reads (aprons included) lies inside the
+// image, so nothing is predicated except the apron load of lanes 0 / 63.
+// COLOR: colour stages fused in (fsr1_color_math.h) — FsrSrtmF on every tap as it is loaded (the role of the
+// FsrRcasInputF callback, ffx_fsr1.h:682), FsrLfgaF / FsrSrtmInvF / FsrTepdC*F on the result before it is stored as FOUT.
+template <int FMT, bool EXACT, bool OPTS, bool INTERIOR, bool COLOR, int FOUT>
+__device__ __forceinline__ void rcas_strip(const RcasArgs& a, int frame, int x0, int y0, int lane) {
+  typedef typename Pixel<FMT>::T texel_t;
+  typedef typename RcasPair<FMT>::T pair_t;
+  typedef typename Pixel<FOUT>::T out_t;
+  typedef typename RcasPair<FOUT>::T out_pair_t;
+  const uint32_t flags = OPTS ? a.flags : 0u;
+  const int W = a.in.width, H = a.in.height;
+  const int col = x0 + 2 * lane;
+  const bool ok0 = INTERIOR || col < W, ok1 = INTERIOR || col + 1 < W;
+  const bool edge = lane == 0 || lane == 63;
+  // apron column of lanes 0 / 63; the other lanes point at their own column so that the interior variant can load
+  // unconditionally (no exec-masked branch: the compiler then counts vmcnt exactly and keeps the prefetch depth)
+  const int hcol = lane == 0 ? x0 - 1 : (lane == 63 ? x0 + kRcasWaveCols : col);
+  const bool halo_ok = edge && (INTERIOR || (hcol >= 0 && hcol < W));
+  const char* const in_col = a.in.base + (long long)frame * a.in.frame_stride + (size_t)col * sizeof(texel_t);
+  const char* const in_hcol = a.in.base + (long long)frame * a.in.frame_stride + (size_t)hcol * sizeof(texel_t);
+  char* const out_col = a.out.base + (long long)frame * a.out.frame_stride + (size_t)col * sizeof(out_t);
+
+  struct row_t { texel_t p0, p1, halo; };
+  auto load = [&](int y, row_t& r) {
+    if (!INTERIOR) r.halo = Pixel<FMT>::zero();
+    if (INTERIOR) {
+      const pair_t pr = *reinterpret_cast<const pair_t*>(in_col + (long long)y * a.in.pitch);
+      __builtin_memcpy(&r.p0, &pr, sizeof(texel_t));
+      __builtin_memcpy(&r.p1, reinterpret_cast<const char*>(&pr) + sizeof(texel_t), sizeof(texel_t));
+      r.halo = *reinterpret_cast<const texel_t*>(in_hcol + (long long)y * a.in.pitch);
+    } else {
+      r.p0 = Pixel<FMT>::zero();
+      r.p1 = Pixel<FMT>::zero();
+      if (y >= 0 && y < H) {  // wave-uniform
+        if (ok1) {
+          const pair_t pr = *reinterpret_cast<const pair_t*>(in_col + (long long)y * a.in.pitch);
+          __builtin_memcpy(&r.p0, &pr, sizeof(texel_t));
+          __builtin_memcpy(&r.p1, reinterpret_cast<const char*>(&pr) + sizeof(texel_t), sizeof(texel_t));
+        } else if (ok0) {
+          r.p0 = *reinterpret_cast<const texel_t*>(in_col + (long long)y * a.in.pitch);
+        }
+        if (halo_ok) r.halo = *reinterpret_cast<const texel_t*>(in_hcol + (long long)y * a.in.pitch);
+      }
+    }
+  };
+  auto rgb = [&](const texel_t& p) {
+    float4_t c = Pixel<FMT>::load(p);
+    if constexpr (COLOR) c = color_prologue<EXACT>(a.color, c);
+    return rgb_t{c.x, c.y, c.z};
+  };
+  // Loop-carried fp32 values reach v_min/v_max through block boundaries, where the compiler no longer knows
+  // they are canonical and would spend a v_max_f32 x,x,x (4.3 cycles) on each; x+0.0 (2.4 cycles) tells it the
+  // same thing.  It turns -0 into +0, so the EXACT variant does not use it.
+  auto known = [](rgb_t v) { return EXACT ? v : rgb_t{v.r + 0.0f, v.g + 0.0f, v.b + 0.0f}; };
+
+  // Ring of raw rows in registers: slot k holds row y0 + r with r % kRing == k; loads run kAhead = kRing - 1 rows
+  // ahead of the arithmetic.  The row loop is unrolled by kRing, so every ring index is static, and rolled
+  // beyond that so the body stays inside the instruction cache.
+  constexpr int kRing = FMT == FSR1_FORMAT_RGBA32F ? 4 : kRcasRing, kAhead = kRing - 1;  // both divide 8
+  row_t q[kRing];
+  rgb_t prev0, prev1, cur0, cur1;
+  {
+    row_t q_prev;
+    load(y0 - 1, q_prev);
+#pragma unroll
+    for (int k = 0; k < kAhead; ++k) load(y0 + k, q[k]);
+    prev0 = rgb(q_prev.p0); prev1 = rgb(q_prev.p1);
+    cur0 = rgb(q[0].p0); cur1 = rgb(q[0].p1);
+  }
+  const float sharp = as_f32(a.con[0]);
+  const int rows = a.rows;
+  const int y_last = y0 + rows;  // the row below the strip is the last one read
+
+#pragma unroll 1
+  for (int r0 = 0; r0 < rows; r0 += kRing) {
+#pragma unroll
+    for (int k = 0; k < kRing; ++k) {
+      const int y = y0 + r0 + k;
+      load(min(y + kAhead, y_last), q[(k + kAhead) % kRing]);  // past the end: re-reads the last row (harmless, branch-free)
+      const row_t& c = q[k];
+      const row_t& n = q[(k + 1) % kRing];
+      const rgb_t next0 = rgb(n.p0), next1 = rgb(n.p1);
+      const rgb_t hal = rgb(c.halo);
+      // horizontal neighbours: pixel 0's left = the left lane's pixel 1, pixel 1's right = the right lane's pixel 0;
+      // lanes 0 / 63 keep their apron texel
+      const rgb_t d0 = neighbour<kDppWaveShr1>(hal, cur1), f1 = neighbour<kDppWaveShl1>(hal, cur0);
+#ifdef FSR1_RCAS_COPY_ONLY  // tuning experiment: memory pattern without the arithmetic
+      rgb_t o0 = {prev0.r + d0.r, cur0.g + next0.g, cur1.b}, o1 = {prev1.r + f1.r, cur1.g + next1.g, cur0.b};
+      (void)sharp;
+#else
+      rgb_t o0 = rcas_pixel<EXACT>(known(prev0), d0, known(cur0), known(cur1), next0, sharp, flags);
+      rgb_t o1 = rcas_pixel<EXACT>(known(prev1), known(cur0), known(cur1), f1, next1, sharp, flags);
+#endif
+      if (INTERIOR || y < H) {
+        const bool alpha = (flags & FSR1_FLAG_RCAS_PASSTHROUGH_ALPHA) != 0;  // :700-705 / FSR_Pass.hlsl:94
+        if constexpr (COLOR) {
+          color_epilogue<EXACT>(a.color, (uint32_t)col, (uint32_t)y, o0.r, o0.g, o0.b);
+          color_epilogue<EXACT>(a.color, (uint32_t)col + 1u, (uint32_t)y, o1.r, o1.g, o1.b);
+        }
+        const out_t t0 = Pixel<FOUT>::store(o0.r, o0.g, o0.b, alpha ? Pixel<FMT>::load(c.p0).w : 1.0f);
+        const out_t t1 = Pixel<FOUT>::store(o1.r, o1.g, o1.b, alpha ? Pixel<FMT>::load(c.p1).w : 1.0f);
+        char* const dst = out_col + (long long)y * a.out.pitch;
+        if (ok1) {
+          out_pair_t pr;
+          __builtin_memcpy(&pr, &t0, sizeof(out_t));
+          __builtin_memcpy(reinterpret_cast<char*>(&pr) + sizeof(out_t), &t1, sizeof(out_t));
+          *reinterpret_cast<out_pair_t*>(dst) = pr;
+        } else if (ok0) {
+          *reinterpret_cast<out_t*>(dst) = t0;
+        }
+      }
+      prev0 = cur0; prev1 = cur1; cur0 = next0; cur1 = next1;
+    }
+  }
+}
+
+// OPTS = false: the plain pass (no denoise / alpha pass-through / HDR square), flags compiled out.
+template <int FMT, bool EXACT, bool OPTS, bool COLOR = false, int FOUT = FMT>
+__global__ void __launch_bounds__(kRcasThreads) rcas_kernel(const RcasArgs a) {
+  const int tiles_per_frame = a.tiles_x * a.tiles_y;
+  const int t = xcd_swizzle(blockIdx.x, tiles_per_frame * a.frames);
+  const int frame = t / tiles_per_frame;
+  const int tf = t - frame * tiles_per_frame;
+  const int ty = tf / a.tiles_x, tx = tf - ty * a.tiles_x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int x0 = tx * kRcasCols + wave * kRcasWaveCols, y0 = ty * a.rows;
+  if (x0 >= a.in.width) return;  // whole wave outside (no barriers in this kernel)
+  const bool interior = x0 >= 1 && x0 + kRcasWaveCols + 1 <= a.in.width && y0 >= 1 && y0 + a.rows + 1 <= a.in.height;
+  if (interior) rcas_strip<FMT, EXACT, OPTS, true, COLOR, FOUT>(a, frame, x0, y0, lane);
+  else rcas_strip<FMT, EXACT, OPTS, false, COLOR, FOUT>(a, frame, x0, y0, lane);
+}
+
+}  // namespace fsr1

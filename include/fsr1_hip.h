@@ -126,6 +126,68 @@ int fsr1_easu_rcas_fused_dispatch(const fsr1_image* in, const fsr1_image* out, c
                                   const uint32_t rcas_con[4], uint32_t flags, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Colour stages either side of the filters: the tone-mapping, film-grain and dither helpers
+ * of ffx-fsr/ffx_fsr1.h:986-1199, as a stand-alone pass and as fused prologue / epilogue of the passes above
+ * (the reference leaves them to the integration's own shaders, e.g. sample/src/DX12/FSR_Tonemapping.hlsl:87).
+ *
+ * Stages run in this fixed order, each only if its bit is set:
+ *   FSR1_COLOR_SRTM      FsrSrtmF     (:1042)  c *= rcp(max3(c) + 1)            HDR {0..FP16_MAX} -> {0..1}
+ *   FSR1_COLOR_LFGA      FsrLfgaF     (:1012)  c += (t*amount) * min(1 - c, c)  t = noise.rgb + grain_bias
+ *   FSR1_COLOR_SRTM_INV  FsrSrtmInvF  (:1044)  c *= rcp(max(1/32768, 1 - max3(c)))
+ *   FSR1_COLOR_TEPD_C8 | FSR1_COLOR_TEPD_C10   FsrTepdC8F / FsrTepdC10F (:1097, :1113): {0..1} linear -> dithered
+ *                        gamma 2.0 on the 8-bit / 10-bit code grid, dither = FsrTepdDitF(pixel, frame) (:1082), or,
+ *                        with FSR1_COLOR_DITHER_FROM_NOISE, saturate(noise.a) (FSR_Tonemapping.hlsl:87).
+ * noise: tiled ("tiled blue noise", :1000) with wrap addressing,
+ *   texel = noise[frame % noise->frames][(y + noise_offset_y) mod height][(x + noise_offset_x) mod width]
+ * in any fsr1_format; signed grain {-0.5..0.5} as float texels with grain_bias 0, or UNORM texels with grain_bias -0.5.
+ * Alpha is not touched by any stage.
+ * Arithmetic: binary32 in the reference's operation order, no contraction; with FSR1_FLAG_MATH_EXACT the two
+ * reciprocals (ARcpF1) are IEEE divisions and every stage is bit-identical to the CPU-evaluated reference,
+ * otherwise they are v_rcp_f32 (1 ulp).  FsrTepd*F's sqrt is correctly rounded in both modes.
+ * ---------------------------------------------------------------------------------------------- */
+enum {
+  FSR1_COLOR_SRTM = 1u << 0,
+  FSR1_COLOR_LFGA = 1u << 1,
+  FSR1_COLOR_SRTM_INV = 1u << 2,
+  FSR1_COLOR_TEPD_C8 = 1u << 3,
+  FSR1_COLOR_TEPD_C10 = 1u << 4,
+  FSR1_COLOR_DITHER_FROM_NOISE = 1u << 5
+};
+
+typedef struct fsr1_color_stages {
+  uint32_t stages;          /* FSR1_COLOR_* bits */
+  float grain_amount;       /* FsrLfgaF `a`, {0..1} */
+  float grain_bias;         /* added to noise.rgb before FsrLfgaF */
+  uint32_t frame;           /* FsrTepdDitF `f`; also selects the noise slice */
+  int32_t noise_offset_x, noise_offset_y;
+  const fsr1_image* noise;  /* required by FSR1_COLOR_LFGA and FSR1_COLOR_DITHER_FROM_NOISE, else may be NULL */
+} fsr1_color_stages;
+
+/* Stand-alone pass: out[frame] = stages(in[frame]); in and out have the same size and may have different formats
+ * (e.g. RGBA16F -> RGBA8_UNORM with FSR1_COLOR_TEPD_C8); in == out (in place) is allowed when the formats match.
+ * flags: FSR1_FLAG_MATH_EXACT or 0. */
+int fsr1_color_dispatch(const fsr1_image* in, const fsr1_image* out, const fsr1_color_stages* stages, uint32_t flags,
+                        void* stream);
+
+/* The passes above with colour stages fused in (no extra trip through HBM):
+ *   prologue  FSR1_COLOR_SRTM is applied to every input texel as it is loaded — the role of a colour transform
+ *             inside the FsrEasu{R,G,B}F gather callbacks (ffx_fsr1.h:234-236) / FsrRcasInputF (:682);
+ *   epilogue  LFGA, SRTM_INV and TEPD are applied to the filter's result (after the optional `c *= c`) before
+ *             it is stored.
+ * fsr1_easu_dispatch_ex takes the prologue and, being the last pass when RCAS is off, the epilogue;
+ * fsr1_rcas_dispatch_ex takes both; fsr1_easu_rcas_fused_dispatch_ex applies the prologue at the EASU loads and
+ * the epilogue after RCAS.  `stages` == NULL (or no bits) is the plain pass.  out->format may differ from
+ * in->format only as RGBA16F -> RGBA8_UNORM / R10G10B10A2_UNORM (the TEPD targets); the EASU->RCAS
+ * intermediary of the fused kernel keeps in->format. */
+int fsr1_easu_dispatch_ex(const fsr1_image* in, const fsr1_image* out, const uint32_t con[16], uint32_t flags,
+                          const fsr1_color_stages* stages, void* stream);
+int fsr1_rcas_dispatch_ex(const fsr1_image* in, const fsr1_image* out, const uint32_t con[4], uint32_t flags,
+                          const fsr1_color_stages* stages, void* stream);
+int fsr1_easu_rcas_fused_dispatch_ex(const fsr1_image* in, const fsr1_image* out, const uint32_t easu_con[16],
+                                     const uint32_t rcas_con[4], uint32_t flags, const fsr1_color_stages* stages,
+                                     void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * FSR_Filter::Upscale (sample/src/DX12/FSR_Filter.cpp:101-141) as one call.
  * ---------------------------------------------------------------------------------------------- */
 typedef struct fsr1_params {

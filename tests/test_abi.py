@@ -72,3 +72,29 @@ def test_product_does_not_link_the_oracle(fsr):
             if f.endswith((".py", ".hip", ".c", ".h", ".cpp")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "cpu_oracle" not in src and "libfsr1_oracle" not in src and "libfsr1_ref" not in src, f
+
+
+def test_colour_stage_validation(fsr):
+    """fsr1_color_dispatch / *_ex reject bad stage descriptors before anything is launched (no GPU needed)."""
+    lib = fsr.load()
+    a = fsr.fsr1_image(0x1000, 16, 16, 0, 1, 0, 0)
+    b = fsr.fsr1_image(0x100000, 16, 16, 0, 1, 0, 0)
+    S = fsr._lib.fsr1_color_stages
+
+    def call(st, flags=0, out=b):
+        return lib.fsr1_color_dispatch(ctypes.byref(a), ctypes.byref(out), ctypes.byref(st), flags, None)
+
+    assert call(S(1 << 9, 0, 0, 0, 0, 0, None)) == -1 and b"unknown colour stage" in lib.fsr1_last_error()
+    assert call(S(8 | 16, 0, 0, 0, 0, 0, None)) == -1 and b"exclusive" in lib.fsr1_last_error()
+    assert call(S(32, 0, 0, 0, 0, 0, None)) == -1 and b"TEPD" in lib.fsr1_last_error()
+    assert call(S(2, 0.5, 0, 0, 0, 0, None)) == -1 and b"noise" in lib.fsr1_last_error()
+    assert call(S(1, 0, 0, 0, 0, 0, None), flags=1) == -1                      # only MATH_EXACT is a colour-pass flag
+    big = fsr.fsr1_image(0x100000, 32, 16, 0, 1, 0, 0)
+    assert call(S(1, 0, 0, 0, 0, 0, None), out=big) == -1 and b"extents" in lib.fsr1_last_error()
+    con = np.zeros(16, np.uint32)
+    p = con.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32))
+    f32 = fsr.fsr1_image(0x100000, 16, 16, 1, 1, 0, 0)
+    st = S(4, 0, 0, 0, 0, 0, None)
+    assert lib.fsr1_rcas_dispatch_ex(ctypes.byref(a), ctypes.byref(f32), p, 0, ctypes.byref(st), None) == -2
+    assert b"format pair" in lib.fsr1_last_error()
+    assert lib.fsr1_rcas_dispatch_ex(ctypes.byref(a), ctypes.byref(b), p, 1 << 5, ctypes.byref(st), None) == -2  # packed fp16 + stages
