@@ -111,7 +111,11 @@ def main():
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--workload", default="1080p_to_4k", choices=sorted(WORKLOADS))
-    ap.add_argument("--pipeline", default="two-pass", choices=["two-pass", "fused", "easu"])
+    ap.add_argument("--pipeline", default="two-pass", choices=["two-pass", "fused", "easu", "color"],
+                    help="color: the stand-alone colour pass (needs --stages) on an output-sized image")
+    ap.add_argument("--stages", type=int, default=0,
+                    help="FSR1_COLOR_* bits fused into the pipeline (SURVEY 8f-N4): 1 SRTM prologue, 2 film grain, 4 SRTM inverse, "
+                         "8 / 16 TEPD 8-bit / 10-bit dither; e.g. 7 = the HDR chain, 10 = grain + 8-bit dither")
     ap.add_argument("--math", default="f", choices=["f", "exact", "h"], help="f: fp32 math (default); exact: reference op order; h: packed fp16")
     ap.add_argument("--storage", default="rgba16f", choices=["rgba16f", "rgba8"],
                     help="image format in HBM: rgba16f (BASELINE's 8 B/pixel) or rgba8 (UNORM, 4 B/pixel; SURVEY 8f-N2)")
@@ -165,18 +169,34 @@ def main():
         srcs.append(t.contiguous())
         mids.append(torch.empty(frames, out_h, out_w, 4, dtype=tdtype, device=device) if args.pipeline == "two-pass" else None)
         dsts.append(torch.empty(frames, out_h, out_w, 4, dtype=tdtype, device=device))
+    stages = None
+    if args.stages:
+        g = torch.Generator(device="cpu").manual_seed(1234)
+        noise = (torch.rand(4, 128, 128, 4, generator=g) - torch.tensor([0.5, 0.5, 0.5, 0.0])).to(torch.float16).to(device)
+        stages = fsr.ColorStages(args.stages, grain_amount=0.25, frame=1, noise=noise)  # 128x128 tiles like the sample's blue noise
+    if args.pipeline == "color":
+        if not stages:
+            raise SystemExit("--pipeline color needs --stages")
+        srcs = [torch.rand(frames, out_h, out_w, 4, device=device).to(tdtype) if tdtype != torch.uint8 else
+                torch.randint(0, 256, (frames, out_h, out_w, 4), device=device, dtype=torch.uint8) for _ in range(ring)]
     easu_con = fsr.FsrEasuCon(in_w, in_h, in_w, in_h, out_w, out_h)
     rcas_con = fsr.FsrRcasCon(0.25)  # sample default attenuation (SampleRenderer.h:49)
+
+    # two-pass: the prologue belongs to EASU's loads, the epilogue to RCAS's stores
+    pre = fsr.ColorStages(args.stages & 1) if args.stages & 1 else None
+    post = fsr.ColorStages(args.stages & ~1, grain_amount=0.25, frame=1, noise=stages.noise) if args.stages & ~1 else None
 
     def step(i):
         s = i % ring
         if args.pipeline == "two-pass":
-            fsr.easu(srcs[s], mids[s], con=easu_con, flags=math_flags)
-            fsr.rcas(mids[s], dsts[s], con=rcas_con, flags=math_flags)
+            fsr.easu(srcs[s], mids[s], con=easu_con, flags=math_flags, stages=pre)
+            fsr.rcas(mids[s], dsts[s], con=rcas_con, flags=math_flags, stages=post)
         elif args.pipeline == "fused":
-            fsr.easu_rcas_fused(srcs[s], dsts[s], easu_con=easu_con, rcas_con=rcas_con, flags=math_flags)
+            fsr.easu_rcas_fused(srcs[s], dsts[s], easu_con=easu_con, rcas_con=rcas_con, flags=math_flags, stages=stages)
+        elif args.pipeline == "color":
+            fsr.color(srcs[s], dsts[s], stages, flags=math_flags)
         else:
-            fsr.easu(srcs[s], dsts[s], con=easu_con, flags=math_flags)
+            fsr.easu(srcs[s], dsts[s], con=easu_con, flags=math_flags, stages=stages)
 
     def fence():
         torch.cuda.synchronize()
@@ -223,19 +243,23 @@ def main():
     kern = {}
     if args.pipeline in ("two-pass", "easu"):
         tgt = mids if args.pipeline == "two-pass" else dsts
-        kern["easu"] = kernel_ms(lambda i: fsr.easu(srcs[i % ring], tgt[i % ring], con=easu_con, flags=math_flags), n_k)
+        kern["easu"] = kernel_ms(lambda i: fsr.easu(srcs[i % ring], tgt[i % ring], con=easu_con, flags=math_flags,
+                                                    stages=pre if args.pipeline == "two-pass" else stages), n_k)
     if args.pipeline == "two-pass":
-        kern["rcas"] = kernel_ms(lambda i: fsr.rcas(mids[i % ring], dsts[i % ring], con=rcas_con, flags=math_flags), n_k)
+        kern["rcas"] = kernel_ms(lambda i: fsr.rcas(mids[i % ring], dsts[i % ring], con=rcas_con, flags=math_flags, stages=post), n_k)
     if args.pipeline == "fused":
-        kern["fused"] = kernel_ms(lambda i: fsr.easu_rcas_fused(srcs[i % ring], dsts[i % ring], easu_con=easu_con, rcas_con=rcas_con, flags=math_flags), n_k)
+        kern["fused"] = kernel_ms(lambda i: fsr.easu_rcas_fused(srcs[i % ring], dsts[i % ring], easu_con=easu_con, rcas_con=rcas_con,
+                                                                flags=math_flags, stages=stages), n_k)
+    if args.pipeline == "color":
+        kern["color"] = kernel_ms(lambda i: fsr.color(srcs[i % ring], dsts[i % ring], stages, flags=math_flags), n_k)
 
     # algorithmic HBM bytes per launch: EASU in+out, RCAS 2*out, fused in+out
-    alg = {"easu": in_bytes + out_bytes, "rcas": 2 * out_bytes, "fused": in_bytes + out_bytes}
+    alg = {"easu": in_bytes + out_bytes, "rcas": 2 * out_bytes, "fused": in_bytes + out_bytes, "color": 2 * out_bytes}
     dominant = max(kern, key=kern.get)
 
     def roof(name):
         gbps = alg[name] / (kern[name] * 1e-3) / 1e9
-        pmc = pmc_traffic(args.workload, args.pipeline, name) if args.math == "f" and args.storage == "rgba16f" else None
+        pmc = pmc_traffic(args.workload, args.pipeline, name) if args.math == "f" and args.storage == "rgba16f" and not args.stages else None
         return {"kernel": name, "bound": "hbm", "achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(gbps / HBM_PEAK_GBPS, 4), "traffic": pmc[0] if pmc else None,
                 "traffic_source": pmc[1] if pmc else None, "algorithmic_bytes": alg[name],
@@ -243,20 +267,21 @@ def main():
 
     if rank == 0:
         line = {
-            "metric": "upscaled megapixels/sec (EASU+RCAS, 1080p->4K fp16)" if args.pipeline != "easu" else "upscaled megapixels/sec (EASU only)",
+            "metric": {"easu": "upscaled megapixels/sec (EASU only)", "color": "megapixels/sec (colour pass)"}.get(
+                args.pipeline, "upscaled megapixels/sec (EASU+RCAS, 1080p->4K fp16)"),
             "value": round(value, 1), "unit": "Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(total["seconds"] * 1e3 / args.steps, 5), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32" if args.math != "h" else "f16", "data": "synthetic",
             "config": {"workload": "%s: %dx%d -> %dx%d %s, %d frame(s)/step/GPU, %s, math=%s, ring of %d frame sets"
                                    % (args.workload, in_w, in_h, out_w, out_h, args.storage.upper(), frames, args.pipeline, args.math, ring),
-                       "pipeline": args.pipeline, "storage": args.storage, "rcas_sharpness_stops": 0.25,
+                       "pipeline": args.pipeline, "storage": args.storage, "color_stages": args.stages, "rcas_sharpness_stops": 0.25,
                        "parallelism": "independent frames per GPU, counters-only collective"},
             "roofline": roof(dominant),
             "kernels": {k: roof(k) for k in kern},
             "pipeline_hbm": {"algorithmic_bytes_per_step": sum(alg[k] for k in kern),
                              "achieved_GBps": round(sum(alg[k] for k in kern) * args.steps / seconds / 1e9, 1)},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.pipeline != "color" and not args.stages:
             line["cpu_baseline"] = cpu_baseline(fsr, in_w, in_h, out_w, out_h)
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -61,6 +61,8 @@ static int check_image(const fsr1_image* im, const char* name, ImageView* v) {
   if (!im->data) return fail(FSR1_ERR_INVALID_ARGUMENT, "%s: null data pointer", name);
   if (im->width <= 0 || im->height <= 0 || im->frames <= 0)
     return fail(FSR1_ERR_INVALID_ARGUMENT, "%s: bad extent %dx%dx%d", name, im->width, im->height, im->frames);
+  if (im->width > (1 << 20) || im->height > (1 << 20))  // pixel coordinates stay exact in binary32 with room to spare
+    return fail(FSR1_ERR_UNSUPPORTED, "%s: extent %dx%d beyond 2^20 pixels per side", name, im->width, im->height);
   if (im->format < FSR1_FORMAT_RGBA16F || im->format > FSR1_FORMAT_R10G10B10A2_UNORM)
     return fail(FSR1_ERR_UNSUPPORTED, "%s: unsupported format %d", name, im->format);
   const size_t px = pixel_bytes(im->format);
@@ -148,6 +150,8 @@ static int check_color(const fsr1_color_stages* st, const char* who, ColorArgs* 
     c->noise.format = st->noise->format;
     c->noise.off_x = (int)((((long long)st->noise_offset_x % nv.width) + nv.width) % nv.width);
     c->noise.off_y = (int)((((long long)st->noise_offset_y % nv.height) + nv.height) % nv.height);
+    c->noise.rcp_width = 1.0f / (float)nv.width;
+    c->noise.rcp_height = 1.0f / (float)nv.height;
   }
   return FSR1_OK;
 }

@@ -50,10 +50,9 @@ __device__ __forceinline__ float FsrTepdDitF(uint32_t px, uint32_t py, uint32_t 
 // ffx_a.h:1499 AGtZeroF1 = saturate(m * +INF): 1 for m > 0, else 0 (0*inf = NaN clamps to 0)
 __device__ __forceinline__ float AGtZeroF1(float m) { return sat(m * __builtin_inff()); }
 
-// :1097-1110 FsrTepdC8F (STEPS = 255) / :1113-1120 FsrTepdC10F (STEPS = 1023), one channel
-template <int STEPS>
-__device__ __forceinline__ float FsrTepdCF1(float c, float dit) {
-  const float k = (float)STEPS, rk = (float)(1.0 / (double)STEPS);
+// :1097-1110 FsrTepdC8F (k = 255) / :1113-1120 FsrTepdC10F (k = 1023), one channel; rk = float(1.0 / k).
+// k and rk are run-time values so that both widths share one copy of the code (it is inlined per pixel).
+__device__ __forceinline__ float FsrTepdCF1(float c, float dit, float k, float rk) {
   float n = sqrtf(c);  // correctly rounded (hipcc default)
   n = floorf(n * k) * rk;
   const float a = n * n;
@@ -63,9 +62,20 @@ __device__ __forceinline__ float FsrTepdCF1(float c, float dit) {
   return sat(n + AGtZeroF1(dit - r) * rk);
 }
 
+// v mod d for v < 2^23 without an integer division (a runtime-divisor `%` expands to ~30 instructions and this runs
+// once or twice per pixel): the float quotient is within one of the true one, the remainder is fixed up.
+__device__ __forceinline__ uint32_t wrap_mod(uint32_t v, uint32_t d, float rcp_d) {
+  const uint32_t q = (uint32_t)((float)v * rcp_d);
+  int32_t r = (int32_t)(v - q * d);
+  r += r < 0 ? (int32_t)d : 0;
+  r -= r >= (int32_t)d ? (int32_t)d : 0;
+  return (uint32_t)r;
+}
+
 // One RGBA texel of the tiled noise texture for pixel (x, y); wrap addressing.
 __device__ __forceinline__ float4_t noise_fetch(const NoiseView& nv, uint32_t x, uint32_t y) {
-  const uint32_t nx = (x + (uint32_t)nv.off_x) % (uint32_t)nv.width, ny = (y + (uint32_t)nv.off_y) % (uint32_t)nv.height;
+  const uint32_t nx = wrap_mod(x + (uint32_t)nv.off_x, (uint32_t)nv.width, nv.rcp_width);
+  const uint32_t ny = wrap_mod(y + (uint32_t)nv.off_y, (uint32_t)nv.height, nv.rcp_height);
   const char* row = nv.base + (long long)ny * nv.pitch;
   switch (nv.format) {
     case FSR1_FORMAT_RGBA16F: return Pixel<FSR1_FORMAT_RGBA16F>::load(reinterpret_cast<const half4_t*>(row)[nx]);
@@ -103,11 +113,9 @@ __device__ __forceinline__ void color_epilogue(const ColorArgs& ca, uint32_t x, 
   if (st & FSR1_COLOR_SRTM_INV) FsrSrtmInvF<EXACT>(r, g, b);
   if (st & (FSR1_COLOR_TEPD_C8 | FSR1_COLOR_TEPD_C10)) {
     const float dit = (st & FSR1_COLOR_DITHER_FROM_NOISE) ? sat(n.w) : FsrTepdDitF(x, y, ca.frame);
-    if (st & FSR1_COLOR_TEPD_C8) {
-      r = FsrTepdCF1<255>(r, dit); g = FsrTepdCF1<255>(g, dit); b = FsrTepdCF1<255>(b, dit);
-    } else {
-      r = FsrTepdCF1<1023>(r, dit); g = FsrTepdCF1<1023>(g, dit); b = FsrTepdCF1<1023>(b, dit);
-    }
+    const bool c8 = (st & FSR1_COLOR_TEPD_C8) != 0;
+    const float k = c8 ? 255.0f : 1023.0f, rk = c8 ? (float)(1.0 / 255.0) : (float)(1.0 / 1023.0);
+    r = FsrTepdCF1(r, dit, k, rk); g = FsrTepdCF1(g, dit, k, rk); b = FsrTepdCF1(b, dit, k, rk);
   }
   r = pinned(r); g = pinned(g); b = pinned(b);  // the narrowing that follows must round these binary32 values
 }

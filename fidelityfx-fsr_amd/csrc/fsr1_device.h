@@ -43,6 +43,7 @@ struct NoiseView {
   long long pitch;
   int format;        // fsr1_format
   int off_x, off_y;  // noise_offset reduced to [0, width) x [0, height) by the host
+  float rcp_width, rcp_height;  // 1.0f / width, 1.0f / height (wrap_mod)
 };
 
 struct ColorArgs {

@@ -89,7 +89,8 @@ __device__ __forceinline__ void rcas_strip(const RcasArgs& a, int frame, int x0,
   // Ring of raw rows in registers: slot k holds row y0 + r with r % kRing == k; loads run kAhead = kRing - 1 rows
   // ahead of the arithmetic.  The row loop is unrolled by kRing, so every ring index is static, and rolled
   // beyond that so the body stays inside the instruction cache.
-  constexpr int kRing = FMT == FSR1_FORMAT_RGBA32F ? 4 : kRcasRing, kAhead = kRing - 1;  // both divide 8
+  // (the colour variants inline two epilogues per row: a shorter unroll keeps them inside the instruction cache)
+  constexpr int kRing = (FMT == FSR1_FORMAT_RGBA32F || COLOR) ? 4 : kRcasRing, kAhead = kRing - 1;  // both divide 8
   row_t q[kRing];
   rgb_t prev0, prev1, cur0, cur1;
   {
