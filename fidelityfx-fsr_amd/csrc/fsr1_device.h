@@ -21,7 +21,10 @@ typedef float float4_t __attribute__((ext_vector_type(4)));
 // Output tile of one 256-thread workgroup (4 waves): 64 x 16 pixels, each wave owns 4 rows, a
 // lane owns one column -> every global store instruction writes 64 consecutive pixels.
 constexpr int kTileW = 64;
-constexpr int kTileH = 16;
+#ifndef FSR1_EASU_TILE_H
+#define FSR1_EASU_TILE_H 16
+#endif
+constexpr int kTileH = FSR1_EASU_TILE_H;  // multiple of 4 (rows are split over the four waves)
 constexpr int kThreads = 256;
 #ifndef FSR1_FUSED_TILE_H
 #define FSR1_FUSED_TILE_H 16

@@ -128,8 +128,8 @@ __global__ void __launch_bounds__(kThreads) easu_h_kernel(const EasuArgs a) {
   const half_t one = (half_t)1.0f, zero = (half_t)0.0f;
 
 #pragma unroll 1
-  for (int r = 0; r < 4; ++r) {
-    const int oy = oy0 + wave * 4 + r;
+  for (int r = 0; r < kTileH / 4; ++r) {
+    const int oy = oy0 + wave * (kTileH / 4) + r;
     if (oy >= a.out.height) break;
     float ppy = (float)oy * c0y + c0w;
     const float fpy = floorf(ppy);

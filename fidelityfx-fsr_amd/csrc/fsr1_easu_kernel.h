@@ -51,8 +51,8 @@ __global__ void __launch_bounds__(kThreads) easu_kernel(const EasuArgs a) {
   const bool hdr = (a.flags & FSR1_FLAG_HDR_SQUARE) != 0;
 
 #pragma unroll 1
-  for (int r = 0; r < 4; ++r) {
-    const int oy = oy0 + wave * 4 + r;
+  for (int r = 0; r < kTileH / 4; ++r) {
+    const int oy = oy0 + wave * (kTileH / 4) + r;
     if (oy >= a.out.height) break;
     float ppy = (float)oy * c0y + c0w;
     const float fpy = floorf(ppy);

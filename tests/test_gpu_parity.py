@@ -304,7 +304,8 @@ def test_fused_through_upscale(fsr, port):
 # ------------------------------------------------------------------------------------------------
 # BASELINE.json full sizes: oracle on row bands + size-independent properties
 # ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("shape", [(1920, 1080, 3840, 2160), (2560, 1440, 3840, 2160)], ids=["1080p_to_4k", "1440p_to_4k"])
+@pytest.mark.parametrize("shape", [(1920, 1080, 3840, 2160), (2560, 1440, 3840, 2160), (3840, 2160, 7680, 4320), (960, 540, 1920, 1080)],
+                         ids=["1080p_to_4k", "1440p_to_4k", "4k_to_8k", "540p_to_1080p"])
 def test_full_size_bands_and_properties(fsr, port, shape):
     iw, ih, ow, oh = shape
     img = frames.synthetic_frame(iw, ih, k=0, dtype=np.float16)
@@ -332,6 +333,32 @@ def test_full_size_bands_and_properties(fsr, port, shape):
     mid2 = torch.zeros_like(mid)
     fsr.easu(src, mid2, con=con)
     assert torch.equal(mid, mid2)
+    # the single-launch pipeline (BASELINE configs[3]) gives the very same image at full size
+    fsr.easu_rcas_fused(src, mid2, easu_con=con, rcas_con=rc)
+    assert torch.equal(out, mid2)
+
+
+def test_batch_sharded_like_config_3(fsr, port):
+    """BASELINE configs[2]: a batch of 1440p->4K frames, 8 per GPU: one launch over frames = 8 equals 8 single-frame
+    launches bit for bit (frames are independent units), and frame k of the batch matches the oracle on a band."""
+    iw, ih, ow, oh, n = 2560, 1440, 3840, 2160, 8
+    base = [dev(frames.synthetic_frame(iw, ih, k=k, dtype=np.float16)) for k in range(2)]
+    src = torch.stack([torch.roll(base[f % 2], shifts=(3 * f, 5 * f), dims=(0, 1)) for f in range(n)]).contiguous()
+    con = fsr.FsrEasuCon(iw, ih, iw, ih, ow, oh)
+    rc = fsr.FsrRcasCon(0.25)
+    batch = torch.zeros(n, oh, ow, 4, dtype=torch.float16, device="cuda")
+    fsr.easu_rcas_fused(src, batch, easu_con=con, rcas_con=rc)
+    one = torch.zeros(oh, ow, 4, dtype=torch.float16, device="cuda")
+    for f in (0, 3, 7):
+        fsr.easu_rcas_fused(src[f], one, easu_con=con, rcas_con=rc)
+        assert torch.equal(batch[f], one), "frame %d of the batch differs from its single-frame launch" % f
+    f, y0 = 5, 1000
+    img32 = host(src[f]).astype(np.float32)
+    mid = torch.zeros(oh, ow, 4, dtype=torch.float16, device="cuda")
+    fsr.easu(src[f], mid, con=con)
+    want = port.rcas_f(host(mid).astype(np.float32), rc, 0, (y0, y0 + 8))[y0:y0 + 8]
+    assert_f_class(host(batch[f])[y0:y0 + 8], want, "batch frame %d" % f)
+    assert_f_class(host(mid)[y0:y0 + 8], port.easu_f(img32, ow, oh, con, 0, (y0, y0 + 8))[y0:y0 + 8], "batch easu frame %d" % f)
 
 
 def test_constant_image_is_a_fixed_point(fsr):
