@@ -25,6 +25,9 @@ for _p in (ROOT, os.path.join(ROOT, "oracle")):
         sys.path.insert(0, _p)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured copy ceiling
+# VALU issue peak: 256 CUs x 4 SIMDs, one wave64 fp32 instruction per 2 cycles at 2.4 GHz (MI355X_MICROARCH.md:
+# "v_fma_f32 (wave64) 2 cyc (SIMD-32)") = 1228.8 G wave-instructions/s = 157.3 TFLOP/s of fp32 FMA
+VALU_PEAK_GINST = 256 * 4 * 2.4 / 2.0
 
 WORKLOADS = {
     # name: (in_w, in_h, out_w, out_h, frames per step per GPU)
@@ -65,7 +68,8 @@ def pmc_traffic(workload, pipeline, kernel_name):
             continue
         for k, v in d.get("kernels", {}).items():
             if ("::%s_kernel<" % kernel_name) in k and "traffic_bytes" in v.get("hbm_per_launch", {}):
-                best = (v["hbm_per_launch"]["traffic_bytes"], os.path.relpath(f, ROOT))
+                best = (v["hbm_per_launch"]["traffic_bytes"], os.path.relpath(f, ROOT),
+                        v.get("pmc_avg_per_launch", {}).get("SQ_INSTS_VALU"))
     return best
 
 
@@ -260,10 +264,21 @@ def main():
     def roof(name):
         gbps = alg[name] / (kern[name] * 1e-3) / 1e9
         pmc = pmc_traffic(args.workload, args.pipeline, name) if args.math == "f" and args.storage == "rgba16f" and not args.stages else None
-        return {"kernel": name, "bound": "hbm", "achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": round(gbps / HBM_PEAK_GBPS, 4), "traffic": pmc[0] if pmc else None,
-                "traffic_source": pmc[1] if pmc else None, "algorithmic_bytes": alg[name],
-                "avg_kernel_us": round(kern[name] * 1e3, 2)}
+        r = {"kernel": name, "bound": "hbm", "achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+             "frac": round(gbps / HBM_PEAK_GBPS, 4), "traffic": pmc[0] if pmc else None,
+             "traffic_source": pmc[1] if pmc else None, "algorithmic_bytes": alg[name],
+             "avg_kernel_us": round(kern[name] * 1e3, 2)}
+        if name in ("easu", "fused"):
+            # the north star's "HBM read-roofline": input bytes only (SURVEY.md 8d asks for both figures, labelled)
+            rd = in_bytes / (kern[name] * 1e-3) / 1e9
+            r["read_only"] = {"achieved": round(rd, 1), "frac": round(rd / HBM_PEAK_GBPS, 4), "algorithmic_bytes": in_bytes}
+        if pmc and pmc[2]:
+            # the wall this kernel is actually on: VALU issue (wave-instructions per launch from the same PMC summary,
+            # SQ_INSTS_VALU, over the live kernel time)
+            gi = pmc[2] / (kern[name] * 1e-3) / 1e9
+            r["valu"] = {"achieved": round(gi, 1), "peak": VALU_PEAK_GINST, "unit": "G wave-inst/s", "frac": round(gi / VALU_PEAK_GINST, 4),
+                         "wave_insts_per_launch": int(pmc[2])}
+        return r
 
     if rank == 0:
         line = {

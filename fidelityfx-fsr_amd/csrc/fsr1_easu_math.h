@@ -55,10 +55,14 @@ __device__ __forceinline__ void easu_stage_footprint(const EasuLds& l, const Ima
     l.tex[i] = float4_t{c.x, c.y, c.z, fmaf(c.z, 0.5f, fmaf(c.x, 0.5f, c.y))};
   }
   __syncthreads();
-  // ---- phase 2: per-texel terms.  Border texels read clamped neighbours and produce values nobody
-  //      uses (the analysis is consumed for columns 1..fw-2 / rows 1..fh-2 only). ----
-  for (int i = tid; i < n; i += kThreads) {
-    const int iu = max(i - fw, 0), id = min(i + fw, n - 1), il = max(i - 1, 0), ir = min(i + 1, n - 1);
+  // ---- phase 2: per-texel terms, for the texels that are read as f/g/j/k of some pixel: columns 1..fw-2, rows
+  //      1..fh-2 of the footprint (every neighbour of those lies inside it, so nothing is clamped). ----
+  const int iw = fw - 2, m = iw * (fh - 2);
+  const float inv_iw = 1.0f / (float)iw;
+  for (int j = tid; j < m; j += kThreads) {
+    const int y = (int)(((float)j + 0.5f) * inv_iw);
+    const int i = (y + 1) * fw + (j - y * iw) + 1;
+    const int iu = i - fw, id = i + fw, il = i - 1, ir = i + 1;
     const float4_t tc = l.tex[i], tr = l.tex[ir], td = l.tex[id];
     // FsrEasuSetF :295-313 — reference order, no contraction
     const float lA = l.tex[iu].w, lB = l.tex[il].w, lC = tc.w, lD = tr.w, lE = td.w;
@@ -77,7 +81,7 @@ __device__ __forceinline__ void easu_stage_footprint(const EasuLds& l, const Ima
       // :416-419 min/max over the 2x2 block whose top-left texel is i (f g / j k).  The texels are binary16
       // values, so their min/max are too: keep them packed and clamp after the final rounding (rounding is
       // monotone, the bounds are representable, so both orders give the same binary16).  .w = 1 forces alpha.
-      const float4_t tdr = l.tex[min(id + 1, n - 1)];
+      const float4_t tdr = l.tex[id + 1];
       const float mnR = fminf(min3f(tc.x, tr.x, td.x), tdr.x), mxR = fmaxf(max3f(tc.x, tr.x, td.x), tdr.x);
       const float mnG = fminf(min3f(tc.y, tr.y, td.y), tdr.y), mxG = fmaxf(max3f(tc.y, tr.y, td.y), tdr.y);
       const float mnB = fminf(min3f(tc.z, tr.z, td.z), tdr.z), mxB = fmaxf(max3f(tc.z, tr.z, td.z), tdr.z);
