@@ -259,7 +259,7 @@ class FSR_Filter:
         self.OnDestroyWindowSizeDependentResources()
         self._created = False
 
-    def Upscale(self, displayWidth, displayHeight, pState, hdr=None, stream=None):
+    def Upscale(self, displayWidth, displayHeight, pState, hdr=None, stream=None, stages=None):
         if self._input is None:
             raise Fsr1Error("OnCreateWindowSizeDependentResources has not been called")
         if not pState.m_nUpscaleType:
@@ -271,8 +271,9 @@ class FSR_Filter:
         if (o.width, o.height) != (displayWidth, displayHeight):
             raise Fsr1Error("display size changed: call OnCreateWindowSizeDependentResources again")
         m = image_of(self.m_intermediary) if self.m_intermediary is not None else None
-        _lib.check(_lib.load().fsr1_upscale(ctypes.byref(i), ctypes.byref(m) if m is not None else None, ctypes.byref(o),
-                                           ctypes.byref(p), _stream_ptr(stream)))
+        sp, _keep = _stages(stages)  # optional ColorStages fused into the passes (fsr1_upscale_ex)
+        _lib.check(_lib.load().fsr1_upscale_ex(ctypes.byref(i), ctypes.byref(m) if m is not None else None, ctypes.byref(o),
+                                              ctypes.byref(p), sp, _stream_ptr(stream)))
         return self._output
 
 

@@ -326,6 +326,11 @@ int fsr1_color_dispatch(const fsr1_image* in, const fsr1_image* out, const fsr1_
 // FSR_Filter::Upscale, sample/src/DX12/FSR_Filter.cpp:101-141.
 int fsr1_upscale(const fsr1_image* in, const fsr1_image* intermediary, const fsr1_image* out, const fsr1_params* p,
                  void* stream) {
+  return fsr1_upscale_ex(in, intermediary, out, p, nullptr, stream);
+}
+
+int fsr1_upscale_ex(const fsr1_image* in, const fsr1_image* intermediary, const fsr1_image* out, const fsr1_params* p,
+                    const fsr1_color_stages* stages, void* stream) {
   if (!in || !out || !p) return fail(FSR1_ERR_INVALID_ARGUMENT, "upscale: null argument");
   uint32_t easu_con[16], rcas_con[4];
   // :106 — viewport == input resource size == (renderWidth, renderHeight); output = display size
@@ -334,18 +339,32 @@ int fsr1_upscale(const fsr1_image* in, const fsr1_image* intermediary, const fsr
   const uint32_t math = p->flags & (FSR1_FLAG_MATH_EXACT | FSR1_FLAG_MATH_PACKED_FP16);
   const uint32_t rcas_opts = p->flags & (FSR1_FLAG_RCAS_DENOISE | FSR1_FLAG_RCAS_PASSTHROUGH_ALPHA);
   if (p->flags & ~(math | rcas_opts)) return fail(FSR1_ERR_INVALID_ARGUMENT, "upscale: params.flags may only hold MATH_* and RCAS_* bits");
+  if (stages && !stages->stages) stages = nullptr;
   if (!p->use_rcas) {
     // :107 Sample.x = hdr && !bUseRcas ; :140 EASU straight into the output
-    return fsr1_easu_dispatch(in, out, easu_con, math | (p->hdr ? FSR1_FLAG_HDR_SQUARE : 0u), stream);
+    return fsr1_easu_dispatch_ex(in, out, easu_con, math | (p->hdr ? FSR1_FLAG_HDR_SQUARE : 0u), stages, stream);
   }
   FsrRcasCon(rcas_con, p->rcas_attenuation);  // :124
   const uint32_t rcas_flags = math | rcas_opts | (p->hdr ? FSR1_FLAG_HDR_SQUARE : 0u);  // :125 Sample.x = hdr
-  if (p->fused) return fsr1_easu_rcas_fused_dispatch(in, out, easu_con, rcas_con, rcas_flags, stream);
+  if (p->fused) return fsr1_easu_rcas_fused_dispatch_ex(in, out, easu_con, rcas_con, rcas_flags, stages, stream);
   if (!intermediary) return fail(FSR1_ERR_INVALID_ARGUMENT, "upscale: two-pass EASU+RCAS needs an intermediary image");
-  int rc = fsr1_easu_dispatch(in, intermediary, easu_con, math, stream);  // :121 (Sample.x = 0 when RCAS follows)
+  // two dispatches: the prologue belongs to EASU's loads, the epilogue to RCAS's stores
+  fsr1_color_stages pre, post;
+  const fsr1_color_stages* pre_p = nullptr;
+  const fsr1_color_stages* post_p = nullptr;
+  if (stages) {
+    pre = *stages;
+    post = *stages;
+    pre.stages = stages->stages & (uint32_t)FSR1_COLOR_SRTM;
+    post.stages = stages->stages & ~(uint32_t)FSR1_COLOR_SRTM;
+    pre.noise = nullptr;
+    if (pre.stages) pre_p = &pre;
+    if (post.stages) post_p = &post;
+  }
+  int rc = fsr1_easu_dispatch_ex(in, intermediary, easu_con, math, pre_p, stream);  // :121 (Sample.x = 0 when RCAS follows)
   if (rc) return rc;
   // :130 the UAV->SRV barrier is stream order here
-  return fsr1_rcas_dispatch(intermediary, out, rcas_con, rcas_flags, stream);  // :131
+  return fsr1_rcas_dispatch_ex(intermediary, out, rcas_con, rcas_flags, post_p, stream);  // :131
 }
 
 int fsr1_selftest(uint32_t* failures) {

@@ -203,6 +203,11 @@ typedef struct fsr1_params {
 int fsr1_upscale(const fsr1_image* in, const fsr1_image* intermediary, const fsr1_image* out,
                  const fsr1_params* params, void* stream);
 
+/* fsr1_upscale with colour stages fused in (NULL = none): the prologue goes to EASU's loads, the epilogue to the
+ * pass that writes `out` (RCAS, or EASU when use_rcas == 0), after the `hdr` square. */
+int fsr1_upscale_ex(const fsr1_image* in, const fsr1_image* intermediary, const fsr1_image* out,
+                    const fsr1_params* params, const fsr1_color_stages* stages, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Diagnostics
  * ---------------------------------------------------------------------------------------------- */

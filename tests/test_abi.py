@@ -98,3 +98,14 @@ def test_colour_stage_validation(fsr):
     assert lib.fsr1_rcas_dispatch_ex(ctypes.byref(a), ctypes.byref(f32), p, 0, ctypes.byref(st), None) == -2
     assert b"format pair" in lib.fsr1_last_error()
     assert lib.fsr1_rcas_dispatch_ex(ctypes.byref(a), ctypes.byref(b), p, 1 << 5, ctypes.byref(st), None) == -2  # packed fp16 + stages
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/fsr1_hip.h is the boundary a C host binds: it must compile as C99 and as C++ with nothing but itself."""
+    import subprocess
+    src = tmp_path / "t.c"
+    src.write_text('#include "fsr1_hip.h"\nint main(void) { fsr1_image i = {0}; fsr1_color_stages s = {0}; fsr1_params p = {0};'
+                   ' return (int)(sizeof i + sizeof s + sizeof p) == 0 || FSR1_HIP_VERSION != 100; }\n')
+    inc = os.path.join(ROOT, "include")
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I", inc, "-fsyntax-only", str(src)])
+    subprocess.check_call(["g++", "-std=c++11", "-Wall", "-Werror", "-I", inc, "-fsyntax-only", "-x", "c++", str(src)])

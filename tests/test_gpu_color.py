@@ -218,3 +218,31 @@ def test_colour_stage_argument_validation(fsr):
         fsr.rcas(src, f32, stages=fsr.ColorStages(4))               # RGBA16F -> RGBA32F is not a built pair
     with pytest.raises(fsr.Fsr1Error, match="format"):
         fsr.rcas(src, f32)                                            # and never without stages
+
+
+@pytest.mark.parametrize("fused", [False, True], ids=["two-pass", "fused"])
+def test_upscale_with_colour_stages(fsr, port, fused):
+    """FSR_Filter::Upscale with stages (fsr1_upscale_ex): prologue on EASU, epilogue on the pass that writes the output;
+    two-pass and fused give the same image, EXACT reproduces the oracle pipeline; with bUseRcas off EASU takes both."""
+    iw, ih, ow, oh = 96, 54, 192, 108
+    img = (frames.synthetic_frame(iw, ih, k=1, dtype=np.float32) ** 2 * 30.0).astype(np.float16)
+    img[..., 3] = 1
+    noise = ((np.random.default_rng(4).random((1, 8, 8, 4)) - 0.5) * np.array([1, 1, 1, 0]) + np.array([0, 0, 0, 0.5])).astype(np.float16)
+    p = dict(amount=0.4, bias=0.0, frame=0, noise_offset=(0, 0))
+    st = 1 | 2 | 4
+    cs = stages_of(fsr, st, dev(noise), p)
+    filt = fsr.FSR_Filter()
+    filt.OnCreate(slowFallback=True, exact=True, fused=fused)
+    dst = torch.zeros(oh, ow, 4, dtype=torch.float16, device="cuda")
+    filt.OnCreateWindowSizeDependentResources(dev(img), dst, ow, oh)
+    filt.Upscale(ow, oh, fsr.State(iw, ih, bUseRcas=True, rcasAttenuation=0.25), stages=cs)
+    con = port.FsrEasuCon(iw, ih, iw, ih, ow, oh)
+    r16 = lambda a: a.astype(np.float16).astype(np.float32)
+    want = pipeline_oracle(port, img.astype(np.float32), ow, oh, con, port.FsrRcasCon(0.25), st, p, noise.astype(np.float32), r16)
+    assert_exact16(host(dst), want, "Upscale + stages")
+    # EASU only
+    filt.Upscale(ow, oh, fsr.State(iw, ih, bUseRcas=False), stages=cs)
+    pre = port.color_f(img.astype(np.float32), 1)
+    want = port.color_f(port.easu_f(pre, ow, oh, con), st & ~1, noise=noise.astype(np.float32), **p)
+    assert_exact16(host(dst), want, "Upscale (EASU only) + stages")
+    filt.OnDestroy()
