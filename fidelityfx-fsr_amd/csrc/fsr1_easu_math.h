@@ -217,9 +217,13 @@ __device__ __forceinline__ typename Pixel<FMT>::T easu_resolve(const EasuLds& l,
     const uint4 mm = l.mm[f_idx];
     half2_t rg = __builtin_convertvector(float2_t{p.r, p.g}, half2_t);  // v_cvt_pk_f16_f32, RTNE
     half2_t b1 = __builtin_convertvector(float2_t{p.b, 1.0f}, half2_t);
-    rg = __builtin_elementwise_min(__builtin_bit_cast(half2_t, mm.z), __builtin_elementwise_max(__builtin_bit_cast(half2_t, mm.x), rg));
-    b1 = __builtin_elementwise_min(__builtin_bit_cast(half2_t, mm.w), __builtin_elementwise_max(__builtin_bit_cast(half2_t, mm.y), b1));
-    const uint2 packed = {__builtin_bit_cast(uint32_t, rg), __builtin_bit_cast(uint32_t, b1)};
+    // v_pk_max_f16 / v_pk_min_f16 written out: through the builtins the compiler first canonicalises the four bounds
+    // it loaded from LDS (v_pk_max_f16 x, x, x each — it cannot know they were produced by a conversion), which
+    // doubles the half-rate instructions of this clamp; the instructions themselves are IEEE maxNum/minNum.
+    uint32_t rgu = __builtin_bit_cast(uint32_t, rg), b1u = __builtin_bit_cast(uint32_t, b1);
+    asm("v_pk_max_f16 %0, %1, %0\n\tv_pk_min_f16 %0, %2, %0" : "+v"(rgu) : "v"(mm.x), "v"(mm.z));
+    asm("v_pk_max_f16 %0, %1, %0\n\tv_pk_min_f16 %0, %2, %0" : "+v"(b1u) : "v"(mm.y), "v"(mm.w));
+    const uint2 packed = {rgu, b1u};
     return __builtin_bit_cast(texel_t, packed);
   }
   const rgbf_t q = easu_resolve_f(l, f_idx, p, hdr_square);

@@ -12,6 +12,11 @@
  *
  *   fsr1_runner [--gpus N] [--frames F] [--in WxH] [--out WxH] [--steps K] [--warmup W]
  *               [--pipeline two-pass|fused|easu] [--math f|exact] [--sharpness STOPS] [--hdr]
+ *               [--stages BITS] [--grain AMOUNT]
+ *
+ * --stages fuses colour stages into the passes (FSR1_COLOR_* bits of fsr1_hip.h: 1 FsrSrtmF on the input, 2 FsrLfgaF
+ * film grain, 4 FsrSrtmInvF, 8 / 16 FsrTepdC8F / FsrTepdC10F dither) — what the sample's colour pass does around the
+ * scaler (sample/src/DX12/FSR_Tonemapping.hlsl:87) — with a 128x128 x 4-slice tiled noise texture generated here.
  */
 #define __HIP_PLATFORM_AMD__ 1
 #include <hip/hip_runtime_api.h>
@@ -30,6 +35,8 @@ typedef struct {
   int pipeline; /* 0 two-pass, 1 fused, 2 easu only */
   uint32_t math;
   float sharpness;
+  uint32_t stages; /* FSR1_COLOR_* */
+  float grain;
 } options_t;
 
 typedef struct {
@@ -146,6 +153,26 @@ static void* worker(void* arg) {
   fsr1_image in = {d_in, o->in_w, o->in_h, FSR1_FORMAT_RGBA16F, nf, 0, 0};
   fsr1_image mid = {d_mid, o->out_w, o->out_h, FSR1_FORMAT_RGBA16F, nf, 0, 0};
   fsr1_image out = {d_out, o->out_w, o->out_h, FSR1_FORMAT_RGBA16F, nf, 0, 0};
+  /* tiled noise for the colour stages: rgb = signed grain in [-0.5, 0.5), a = dither in [0, 1) */
+  enum { NOISE_W = 128, NOISE_H = 128, NOISE_S = 4 };
+  void* d_noise = NULL;
+  fsr1_image noise = {NULL, NOISE_W, NOISE_H, FSR1_FORMAT_RGBA16F, NOISE_S, 0, 0};
+  fsr1_color_stages stages = {o->stages, o->grain, 0.0f, 0u, 0, 0, NULL};
+  if (o->stages & (FSR1_COLOR_LFGA | FSR1_COLOR_DITHER_FROM_NOISE)) {
+    const size_t n = (size_t)NOISE_W * NOISE_H * NOISE_S;
+    uint16_t* hn = (uint16_t*)malloc(n * 8);
+    if (!hn) { snprintf(w->error, sizeof w->error, "out of host memory"); w->status = -1; return NULL; }
+    for (size_t i = 0; i < n; ++i)
+      for (int c = 0; c < 4; ++c) {
+        const float u = (float)(mix32((uint32_t)i, (uint32_t)c, 0xC0FFEEu) >> 8) * (1.0f / 16777216.0f);
+        hn[i * 4 + c] = half_from_float(c < 3 ? u - 0.5f : u);
+      }
+    HIP_OK(w, hipMalloc(&d_noise, n * 8));
+    HIP_OK(w, hipMemcpy(d_noise, hn, n * 8, hipMemcpyHostToDevice));
+    free(hn);
+    noise.data = d_noise;
+    stages.noise = &noise;
+  }
   fsr1_params p;
   memset(&p, 0, sizeof p);
   p.render_width = (float)o->in_w;
@@ -161,9 +188,12 @@ static void* worker(void* arg) {
   HIP_OK(w, hipEventCreate(&ev1));
   float ms = 0.f;
   if (nf > 0) {
-    for (int i = 0; i < o->warmup; ++i) FSR_OK(w, fsr1_upscale(&in, o->pipeline == 0 ? &mid : NULL, &out, &p, stream));
+    for (int i = 0; i < o->warmup; ++i) FSR_OK(w, fsr1_upscale_ex(&in, o->pipeline == 0 ? &mid : NULL, &out, &p, &stages, stream));
     HIP_OK(w, hipEventRecord(ev0, stream));
-    for (int i = 0; i < o->steps; ++i) FSR_OK(w, fsr1_upscale(&in, o->pipeline == 0 ? &mid : NULL, &out, &p, stream));
+    for (int i = 0; i < o->steps; ++i) {
+      stages.frame = (uint32_t)i; /* the grain / dither pattern changes every frame (ffx_fsr1.h:1006) */
+      FSR_OK(w, fsr1_upscale_ex(&in, o->pipeline == 0 ? &mid : NULL, &out, &p, &stages, stream));
+    }
     HIP_OK(w, hipEventRecord(ev1, stream));
     HIP_OK(w, hipEventSynchronize(ev1));
     HIP_OK(w, hipEventElapsedTime(&ms, ev0, ev1));
@@ -182,7 +212,7 @@ static void* worker(void* arg) {
   if (w->rank == 0) HIP_OK(w, hipMemcpy(w->gathered, d_recv, sizeof w->counters * o->gpus, hipMemcpyDeviceToHost));
 
   (void)hipFree(d_send); (void)hipFree(d_recv);
-  (void)hipFree(d_in); (void)hipFree(d_mid); (void)hipFree(d_out);
+  (void)hipFree(d_in); (void)hipFree(d_mid); (void)hipFree(d_out); (void)hipFree(d_noise);
   (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1);
   (void)hipStreamDestroy(stream);
   return NULL;
@@ -193,11 +223,12 @@ static int parse_size(const char* s, int* w, int* h) { return sscanf(s, "%dx%d",
 static void usage(void) {
   puts("usage: fsr1_runner [--gpus N] [--frames F] [--in WxH] [--out WxH] [--steps K] [--warmup W]\n"
        "                   [--pipeline two-pass|fused|easu] [--math f|exact] [--sharpness STOPS] [--hdr]\n"
+       "                   [--stages BITS] [--grain AMOUNT]   (colour stages: 1 SRTM, 2 grain, 4 SRTM inverse, 8/16 TEPD 8/10-bit)\n"
        "defaults: 1 GPU, 1 frame per GPU, 1920x1080 -> 3840x2160, 100 steps, 10 warmup, two-pass, f, 0.25 stops");
 }
 
 int main(int argc, char** argv) {
-  options_t o = {1, 0, 1920, 1080, 3840, 2160, 100, 10, 0, 0, 0u, 0.25f};
+  options_t o = {1, 0, 1920, 1080, 3840, 2160, 100, 10, 0, 0, 0u, 0.25f, 0u, 0.25f};
   for (int i = 1; i < argc; ++i) {
     const char* a = argv[i];
     const char* v = i + 1 < argc ? argv[i + 1] : NULL;
@@ -209,6 +240,8 @@ int main(int argc, char** argv) {
     else if (!strcmp(a, "--steps")) { o.steps = atoi(v); ++i; }
     else if (!strcmp(a, "--warmup")) { o.warmup = atoi(v); ++i; }
     else if (!strcmp(a, "--sharpness")) { o.sharpness = (float)atof(v); ++i; }
+    else if (!strcmp(a, "--stages")) { o.stages = (uint32_t)strtoul(v, NULL, 0); ++i; }
+    else if (!strcmp(a, "--grain")) { o.grain = (float)atof(v); ++i; }
     else if (!strcmp(a, "--in")) { if (!parse_size(v, &o.in_w, &o.in_h)) { fprintf(stderr, "bad --in %s\n", v); return 2; } ++i; }
     else if (!strcmp(a, "--out")) { if (!parse_size(v, &o.out_w, &o.out_h)) { fprintf(stderr, "bad --out %s\n", v); return 2; } ++i; }
     else if (!strcmp(a, "--pipeline")) {
@@ -254,10 +287,10 @@ int main(int argc, char** argv) {
     const size_t in_b = (size_t)o.in_w * o.in_h * 8, out_b = (size_t)o.out_w * o.out_h * 8;
     const double bytes = (double)frames * (double)(o.pipeline == 0 ? in_b + 3 * out_b : in_b + out_b);
     printf("{\"metric\": \"upscaled megapixels/sec\", \"value\": %.1f, \"unit\": \"Mpix/s\", \"n_gpus\": %d, \"frames\": %llu, "
-           "\"steps\": %d, \"seconds\": %.6f, \"in\": \"%dx%d\", \"out\": \"%dx%d\", \"pipeline\": \"%s\", \"math\": \"%s\", "
+           "\"steps\": %d, \"seconds\": %.6f, \"in\": \"%dx%d\", \"out\": \"%dx%d\", \"pipeline\": \"%s\", \"math\": \"%s\", \"color_stages\": %u, "
            "\"algorithmic_GBps\": %.1f, \"hbm_peak_frac\": %.4f, \"per_gpu_ms\": [",
            (double)pixels / sec / 1e6, o.gpus, (unsigned long long)frames, o.steps, sec, o.in_w, o.in_h, o.out_w, o.out_h,
-           o.pipeline == 0 ? "two-pass" : (o.pipeline == 1 ? "fused" : "easu"), o.math ? "exact" : "f", bytes / sec / 1e9,
+           o.pipeline == 0 ? "two-pass" : (o.pipeline == 1 ? "fused" : "easu"), o.math ? "exact" : "f", o.stages, bytes / sec / 1e9,
            bytes / sec / 1e9 / (8000.0 * o.gpus));
     for (int i = 0; i < o.gpus; ++i) printf("%s%.3f", i ? ", " : "", (double)gathered[3 * i + 2] * 1e-6);
     printf("]}\n");

@@ -34,3 +34,13 @@ def test_runner_on_gpu(runner, pipeline):
     d = json.loads(out.stdout.strip().splitlines()[-1])
     assert d["n_gpus"] == 1 and d["frames"] == 60 and d["pipeline"] == pipeline
     assert d["value"] > 1000.0  # Mpix/s; the CPU reference does ~25 on 128 cores
+
+
+@pytest.mark.gpu
+def test_runner_with_colour_stages(runner):
+    """--stages: SRTM prologue + film grain + SRTM inverse fused into the single-launch pipeline, from the C host."""
+    out = subprocess.run([runner, "--gpus", "1", "--frames", "2", "--in", "640x360", "--out", "1280x720", "--steps", "10",
+                          "--warmup", "2", "--pipeline", "fused", "--stages", "7", "--grain", "0.3"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    d = json.loads(out.stdout.strip().splitlines()[-1])
+    assert d["color_stages"] == 7 and d["frames"] == 20 and d["value"] > 1000.0
