@@ -33,6 +33,7 @@ WORKLOADS = {
     # name: (in_w, in_h, out_w, out_h, frames per step per GPU)
     "1080p_to_4k": (1920, 1080, 3840, 2160, 1),          # BASELINE configs[1] (and [3] when --pipeline fused)
     "540p_to_1080p": (960, 540, 1920, 1080, 1),          # configs[0] shape
+    "270p_to_540p": (480, 270, 960, 540, 1),             # a launch-bound size (see --graph)
     "1440p_to_4k_x8": (2560, 1440, 3840, 2160, 8),       # configs[2]: 64 frames over 8 GPUs
     "4k_to_8k_x16": (3840, 2160, 7680, 4320, 16),        # configs[4]: 128 frames over 8 GPUs
 }
@@ -123,6 +124,9 @@ def main():
     ap.add_argument("--math", default="f", choices=["f", "exact", "h"], help="f: fp32 math (default); exact: reference op order; h: packed fp16")
     ap.add_argument("--storage", default="rgba16f", choices=["rgba16f", "rgba8"],
                     help="image format in HBM: rgba16f (BASELINE's 8 B/pixel) or rgba8 (UNORM, 4 B/pixel; SURVEY 8f-N2)")
+    ap.add_argument("--graph", type=int, default=0,
+                    help="capture this many consecutive steps into one hipGraph and replay it (launch-bound small frames, SURVEY H9); "
+                         "--steps is rounded down to a multiple of it")
     ap.add_argument("--ring", type=int, default=0, help="distinct frame sets to rotate over (0 = enough to exceed 256 MiB)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -221,11 +225,26 @@ def main():
     for i in range(args.warmup):
         step(i)
     fence()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i)
-    fence()
-    seconds = time.perf_counter() - t0
+    if args.graph > 0:
+        # K steps = K / graph replays of a hipGraph holding `graph` consecutive steps (ring slots 0 .. graph-1, ...)
+        args.steps = max(args.graph, args.steps // args.graph * args.graph)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for i in range(args.graph):
+                step(i)
+        g.replay()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps // args.graph):
+            g.replay()
+        fence()
+        seconds = time.perf_counter() - t0
+    else:
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step(args.warmup + i)
+        fence()
+        seconds = time.perf_counter() - t0
 
     total = reduce_counters(frames * args.steps, frames * args.steps * out_w * out_h, seconds, device)
     value = total["pixels"] / total["seconds"] / 1e6
@@ -308,7 +327,7 @@ def main():
             "vs_baseline": None, "dtype": "f32" if args.math != "h" else "f16", "data": "synthetic",
             "config": {"workload": "%s: %dx%d -> %dx%d %s, %d frame(s)/step/GPU, %s, math=%s, ring of %d frame sets"
                                    % (args.workload, in_w, in_h, out_w, out_h, args.storage.upper(), frames, args.pipeline, args.math, ring),
-                       "pipeline": args.pipeline, "storage": args.storage, "color_stages": args.stages, "rcas_sharpness_stops": 0.25,
+                       "pipeline": args.pipeline, "storage": args.storage, "color_stages": args.stages, "hip_graph_steps": args.graph, "rcas_sharpness_stops": 0.25,
                        "parallelism": "independent frames per GPU, counters-only collective"},
             "roofline": roof(dominant),
             "kernels": {k: roof(k) for k in kern},

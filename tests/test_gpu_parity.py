@@ -375,3 +375,37 @@ def test_constant_image_is_a_fixed_point(fsr):
         fsr.rcas(mid, out)
         inner = host(out)[1:-1, 1:-1, :3].astype(np.float32)
         assert np.abs(inner - np.float32(np.float16(val))).max() <= 0.005 * val + 1e-7
+
+
+def test_dispatches_are_graph_capturable(fsr):
+    """the passes are plain asynchronous launches on the caller's stream, so a frame loop can be captured
+    into a hipGraph and replayed (launch-bound small frames); replay gives the very same image."""
+    iw, ih, ow, oh = 320, 180, 640, 360
+    src = dev(frames.synthetic_frame(iw, ih, k=3, dtype=np.float16))
+    mid = torch.zeros(oh, ow, 4, dtype=torch.float16, device="cuda")
+    eager = torch.zeros_like(mid)
+    fus = torch.zeros_like(mid)
+    con, rc = fsr.FsrEasuCon(iw, ih, iw, ih, ow, oh), fsr.FsrRcasCon(0.25)
+    fsr.easu(src, mid, con=con)
+    fsr.rcas(mid, eager, con=rc)
+    torch.cuda.synchronize()
+    out = torch.zeros_like(mid)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        fsr.easu(src, mid, con=con)
+        fsr.rcas(mid, out, con=rc)
+        fsr.easu_rcas_fused(src, fus, easu_con=con, rcas_con=rc)
+    out.zero_()
+    fus.zero_()
+    mid.zero_()
+    for _ in range(3):
+        g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, eager) and torch.equal(fus, eager)
+    # new input contents, same buffers: the graph recomputes
+    src.copy_(dev(frames.synthetic_frame(iw, ih, k=4, dtype=np.float16)))
+    g.replay()
+    fsr.easu(src, mid, con=con)
+    fsr.rcas(mid, eager, con=rc)
+    torch.cuda.synchronize()
+    assert torch.equal(out, eager)
