@@ -129,6 +129,7 @@ def main():
                          "--steps is rounded down to a multiple of it")
     ap.add_argument("--ring", type=int, default=0, help="distinct frame sets to rotate over (0 = enough to exceed 256 MiB)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fast-paths", action="store_true", help="FSR1_FLAG_NO_FAST_PATHS: generic kernels only (A/B of the exact-2x variants)")
     args = ap.parse_args()
 
     import numpy as np
@@ -155,6 +156,8 @@ def main():
 
     in_w, in_h, out_w, out_h, frames = WORKLOADS[args.workload]
     math_flags = {"f": 0, "exact": fsr.FLAG_MATH_EXACT, "h": fsr.FLAG_MATH_PACKED_FP16}[args.math]
+    if args.no_fast_paths:
+        math_flags |= fsr.FLAG_NO_FAST_PATHS
     px = 8 if args.storage == "rgba16f" else 4
     tdtype = torch.float16 if args.storage == "rgba16f" else torch.uint8
     if args.storage != "rgba16f" and args.math == "h":

@@ -11,7 +11,7 @@
 #include "fsr1_device.h"
 
 namespace fsr1 {
-hipError_t easu_launch(const EasuArgs& a, int fmt, bool exact, hipStream_t stream);
+hipError_t easu_launch(const EasuArgs& a, int fmt, bool exact, bool s2, hipStream_t stream);
 size_t easu_lds_bytes(int fmt, int fp_w, int fp_h);
 hipError_t rcas_launch(const RcasArgs& a, int fmt, bool exact, hipStream_t stream);
 void rcas_geometry(int width, int height, int frames, int* tiles_x, int* tiles_y, int* rows);
@@ -112,7 +112,7 @@ static int footprint_extent(int out_size, int tile, int apron, float scale, floa
 }
 
 static const uint32_t kKnownFlags = FSR1_FLAG_HDR_SQUARE | FSR1_FLAG_RCAS_DENOISE | FSR1_FLAG_RCAS_PASSTHROUGH_ALPHA |
-                                    FSR1_FLAG_MATH_EXACT | FSR1_FLAG_MATH_PACKED_FP16;
+                                    FSR1_FLAG_MATH_EXACT | FSR1_FLAG_MATH_PACKED_FP16 | FSR1_FLAG_NO_FAST_PATHS;
 
 static int check_flags(uint32_t flags) {
   if (flags & ~kKnownFlags) return fail(FSR1_ERR_INVALID_ARGUMENT, "unknown flag bits 0x%x", flags & ~kKnownFlags);
@@ -208,6 +208,17 @@ int fsr1_easu_dispatch_ex(const fsr1_image* in, const fsr1_image* out, const uin
   a.tiles_y = (out->height + kTileH - 1) / kTileH;
   a.frames = out->frames;
   a.flags = flags;
+  // Exact 2x with the viewport covering the input — con0 = {1/2, 1/2, -1/4, -1/4}, what FsrEasuCon gives for
+  // out = 2 * in — takes the variant whose lanes own 2x2 output quads; its tiles are shifted by one pixel, hence one
+  // more tile per axis when the size is a multiple of the tile, and the footprint of a tile is 64/2+3 x 16/2+3 texels.
+  const bool s2 = con[0] == 0x3f000000u && con[1] == 0x3f000000u && con[2] == 0xbe800000u && con[3] == 0xbe800000u &&
+                  !(flags & (FSR1_FLAG_NO_FAST_PATHS | FSR1_FLAG_MATH_PACKED_FP16)) && !a.color.stages && kTileH % 16 == 0;
+  if (s2) {
+    a.tiles_x = (out->width + 1 + kTileW - 1) / kTileW;
+    a.tiles_y = (out->height + 1 + kTileH - 1) / kTileH;
+    a.fp_w = kTileW / 2 + 3;
+    a.fp_h = kTileH / 2 + 3;
+  }
   hipError_t e;
   if (flags & FSR1_FLAG_MATH_PACKED_FP16) {
     if (in->format != FSR1_FORMAT_RGBA16F) return fail(FSR1_ERR_UNSUPPORTED, "easu: packed-fp16 math needs RGBA16F images");
@@ -215,7 +226,7 @@ int fsr1_easu_dispatch_ex(const fsr1_image* in, const fsr1_image* out, const uin
   } else if (a.color.stages) {
     e = easu_color_launch(a, in->format, out->format, (flags & FSR1_FLAG_MATH_EXACT) != 0, static_cast<hipStream_t>(stream));
   } else {
-    e = easu_launch(a, in->format, (flags & FSR1_FLAG_MATH_EXACT) != 0, static_cast<hipStream_t>(stream));
+    e = easu_launch(a, in->format, (flags & FSR1_FLAG_MATH_EXACT) != 0, s2, static_cast<hipStream_t>(stream));
   }
   if (e != hipSuccess) return hip_fail(e, "easu launch");
   return FSR1_OK;
@@ -336,7 +347,7 @@ int fsr1_upscale_ex(const fsr1_image* in, const fsr1_image* intermediary, const 
   // :106 — viewport == input resource size == (renderWidth, renderHeight); output = display size
   FsrEasuCon(easu_con, easu_con + 4, easu_con + 8, easu_con + 12, p->render_width, p->render_height, p->render_width,
              p->render_height, (float)out->width, (float)out->height);
-  const uint32_t math = p->flags & (FSR1_FLAG_MATH_EXACT | FSR1_FLAG_MATH_PACKED_FP16);
+  const uint32_t math = p->flags & (FSR1_FLAG_MATH_EXACT | FSR1_FLAG_MATH_PACKED_FP16 | FSR1_FLAG_NO_FAST_PATHS);
   const uint32_t rcas_opts = p->flags & (FSR1_FLAG_RCAS_DENOISE | FSR1_FLAG_RCAS_PASSTHROUGH_ALPHA);
   if (p->flags & ~(math | rcas_opts)) return fail(FSR1_ERR_INVALID_ARGUMENT, "upscale: params.flags may only hold MATH_* and RCAS_* bits");
   if (stages && !stages->stages) stages = nullptr;

@@ -34,8 +34,11 @@ size_t easu_lds_bytes(int fmt, int fp_w, int fp_h) {
   return (size_t)fp_w * fp_h * kEasuLdsPerTexel;
 }
 
-hipError_t easu_launch(const EasuArgs& a, int fmt, bool exact, hipStream_t stream) {
-#define FSR1_LAUNCH_E(F) return exact ? easu_launch_one<F, true, false, F>(a, stream) : easu_launch_one<F, false, false, F>(a, stream)
+// s2: launch the exact-2x variant (the caller has checked con0 and laid the grid out for the shifted tiles).
+hipError_t easu_launch(const EasuArgs& a, int fmt, bool exact, bool s2, hipStream_t stream) {
+#define FSR1_LAUNCH_E(F)                                                                                                \
+  return s2 ? (exact ? easu_launch_one<F, true, false, F, true>(a, stream) : easu_launch_one<F, false, false, F, true>(a, stream)) \
+            : (exact ? easu_launch_one<F, true, false, F, false>(a, stream) : easu_launch_one<F, false, false, F, false>(a, stream))
   switch (fmt) {
     case FSR1_FORMAT_RGBA16F: FSR1_LAUNCH_E(FSR1_FORMAT_RGBA16F);
     case FSR1_FORMAT_RGBA32F: FSR1_LAUNCH_E(FSR1_FORMAT_RGBA32F);

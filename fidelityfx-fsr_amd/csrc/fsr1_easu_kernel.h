@@ -11,7 +11,15 @@ size_t easu_lds_bytes(int fmt, int fp_w, int fp_h);
 // COLOR: colour stages fused in (fsr1_color_math.h) — FsrSrtmF on every input texel as it is loaded, and
 // FsrLfgaF / FsrSrtmInvF / FsrTepdC*F on the result before it is stored as FOUT.  COLOR = false is the plain pass
 // (FOUT == FMT), compiled without any of it.
-template <int FMT, bool EXACT, bool COLOR = false, int FOUT = FMT>
+//
+// S2: the scale is exactly 2x with the viewport covering the input (con0 = {1/2, 1/2, -1/4, -1/4}).  Output pixels
+// 2j+1 and 2j+2 then share the input texel f = j, with sub-texel positions 1/4 and 3/4 (ffx_fsr1.h:324-326 is exact for
+// these constants), per axis.  Tiles are shifted by one pixel — tile (tx, ty) covers [64 tx - 1, 64 tx + 62] x
+// [16 ty - 1, 16 ty + 14] — so that each holds exactly 32 x 8 such quads, one per lane: window address and position
+// arithmetic are done once per four pixels and (ppx, ppy) are compile-time constants, which folds the bilinear weights
+// and the tap offsets of easu_pixel (-12 % VALU instructions, same four-pixels-per-lane balance).  The arithmetic per
+// pixel is the same function on the same values: bit-identical to S2 = false (tests/test_gpu_parity.py).
+template <int FMT, bool EXACT, bool COLOR = false, int FOUT = FMT, bool S2 = false>
 __global__ void __launch_bounds__(kThreads) easu_kernel(const EasuArgs a) {
   typedef typename Pixel<FOUT>::T texel_t;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -22,15 +30,16 @@ __global__ void __launch_bounds__(kThreads) easu_kernel(const EasuArgs a) {
   const int frame = t / tiles_per_frame;
   const int tf = t - frame * tiles_per_frame;
   const int ty = tf / a.tiles_x, tx = tf - ty * a.tiles_x;
-  const int ox0 = tx * kTileW, oy0 = ty * kTileH;
+  const int ox0 = tx * kTileW - (S2 ? 1 : 0), oy0 = ty * kTileH - (S2 ? 1 : 0);
 
   const float c0x = as_f32(a.con[0]), c0y = as_f32(a.con[1]), c0z = as_f32(a.con[2]), c0w = as_f32(a.con[3]);
 
   // Footprint of this tile: fp(first pixel)-1 .. fp(last pixel)+2 per axis (ffx_fsr1.h:324-342).
   // Same arithmetic as the per-pixel position below, and x -> x*c+b is monotone under rounding.
+  const int oxf = max(ox0, 0), oyf = max(oy0, 0);  // first pixel of the tile inside the image (S2 tiles start at -1)
   const int oxl = min(ox0 + kTileW, a.out.width) - 1, oyl = min(oy0 + kTileH, a.out.height) - 1;
-  const int fx0 = (int)floorf((float)ox0 * c0x + c0z) - 1;
-  const int fy0 = (int)floorf((float)oy0 * c0y + c0w) - 1;
+  const int fx0 = (int)floorf((float)oxf * c0x + c0z) - 1;
+  const int fy0 = (int)floorf((float)oyf * c0y + c0w) - 1;
   const int fw = min((int)floorf((float)oxl * c0x + c0z) + 2 - fx0 + 1, a.fp_w);
   const int fh = min((int)floorf((float)oyl * c0y + c0w) + 2 - fy0 + 1, a.fp_h);
   l.fw = fw;
@@ -38,8 +47,43 @@ __global__ void __launch_bounds__(kThreads) easu_kernel(const EasuArgs a) {
   const int tid = threadIdx.x;
   easu_stage_footprint<FMT, COLOR, EXACT>(l, a.in, a.in.base + (long long)frame * a.in.frame_stride, fx0, fy0, fw, fh, tid, &a.color);
 
-  // ---- phase 3: output pixels; a lane owns a column, a wave 4 rows ----
+  // ---- phase 3: output pixels; a lane owns a column, a wave 4 rows (S2: a lane owns a 2x2 quad, a wave 2 quad rows) ----
   const int lane = tid & 63, wave = tid >> 6;
+  if constexpr (S2) {
+    static_assert(!COLOR && kTileW == 64 && kTileH % 8 == 0, "the exact-2x variant is built for the plain 64-wide tiles");
+    const int W = a.out.width, H = a.out.height;
+    const bool hdr = (a.flags & FSR1_FLAG_HDR_SQUARE) != 0;
+    struct __attribute__((aligned(sizeof(texel_t)))) pair_t { texel_t p[2]; };
+#pragma unroll 1
+    for (int k = 0; k < kTileH / 16; ++k) {
+      const int qx = lane & 31, qy = (kTileH / 8) * wave + 2 * k + (lane >> 5);
+      const int oxa = ox0 + 2 * qx, oya = oy0 + 2 * qy;  // odd (ox0, oy0 are): the quad is {oxa, oxa+1} x {oya, oya+1}
+      const bool xin0 = oxa >= 0 && oxa < W, xin1 = oxa + 1 < W, yin0 = oya >= 0 && oya < H, yin1 = oya + 1 < H;
+      if (!((xin0 || xin1) && (yin0 || yin1))) continue;
+      const int f_idx = (((oya - 1) >> 1) - fy0) * fw + (((oxa - 1) >> 1) - fx0);  // fp = (o - 1) / 2 for odd o, also for o = -1
+      char* const o0 = a.out.base + (long long)frame * a.out.frame_stride + (long long)oya * a.out.pitch + (long long)oxa * (long long)sizeof(texel_t);
+      if (xin0 && xin1 && yin0 && yin1) {
+        // the whole quad lies inside the image (every lane of every tile but those on the image's border): no
+        // predicates, so the 16 LDS loads of the window are shared by the four pixels
+        pair_t r0, r1;
+        r0.p[0] = easu_resolve<FMT, EXACT>(l, f_idx, easu_pixel<EXACT>(l, f_idx, 0.25f, 0.25f), hdr);
+        r0.p[1] = easu_resolve<FMT, EXACT>(l, f_idx, easu_pixel<EXACT>(l, f_idx, 0.75f, 0.25f), hdr);
+        r1.p[0] = easu_resolve<FMT, EXACT>(l, f_idx, easu_pixel<EXACT>(l, f_idx, 0.25f, 0.75f), hdr);
+        r1.p[1] = easu_resolve<FMT, EXACT>(l, f_idx, easu_pixel<EXACT>(l, f_idx, 0.75f, 0.75f), hdr);
+        *reinterpret_cast<pair_t*>(o0) = r0;
+        *reinterpret_cast<pair_t*>(o0 + a.out.pitch) = r1;
+        continue;
+      }
+      auto row = [&](char* o, bool yin, float ppy) {
+        if (!yin) return;
+        if (xin0) *reinterpret_cast<texel_t*>(o) = easu_resolve<FMT, EXACT>(l, f_idx, easu_pixel<EXACT>(l, f_idx, 0.25f, ppy), hdr);
+        if (xin1) *reinterpret_cast<texel_t*>(o + sizeof(texel_t)) = easu_resolve<FMT, EXACT>(l, f_idx, easu_pixel<EXACT>(l, f_idx, 0.75f, ppy), hdr);
+      };
+      row(o0, yin0, 0.25f);
+      row(o0 + a.out.pitch, yin1, 0.75f);
+    }
+    return;
+  }
   const int ox = ox0 + lane;
   if (ox >= a.out.width) return;
   char* const out_col = a.out.base + (long long)frame * a.out.frame_stride + (size_t)ox * sizeof(texel_t);
@@ -70,16 +114,16 @@ __global__ void __launch_bounds__(kThreads) easu_kernel(const EasuArgs a) {
   }
 }
 
-template <int FMT, bool EXACT, bool COLOR, int FOUT>
+template <int FMT, bool EXACT, bool COLOR, int FOUT, bool S2 = false>
 hipError_t easu_launch_one(const EasuArgs& a, hipStream_t stream) {
   const dim3 grid((unsigned)(a.tiles_x * a.tiles_y * a.frames)), block(kThreads);
   const size_t lds = easu_lds_bytes(FMT, a.fp_w, a.fp_h);
   if (lds > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&easu_kernel<FMT, EXACT, COLOR, FOUT>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&easu_kernel<FMT, EXACT, COLOR, FOUT, S2>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL((easu_kernel<FMT, EXACT, COLOR, FOUT>), grid, block, lds, stream, a);
+  hipLaunchKernelGGL((easu_kernel<FMT, EXACT, COLOR, FOUT, S2>), grid, block, lds, stream, a);
   return hipGetLastError();
 }
 

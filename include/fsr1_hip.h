@@ -93,7 +93,11 @@ enum {
    * PACKED_FP16: the FsrEasuH / FsrRcasH entry points — packed binary16 arithmetic
    * (v_pk_*_f16), parity class "H" (vs the reference's CPU-evaluated H path). */
   FSR1_FLAG_MATH_EXACT = 1u << 4,
-  FSR1_FLAG_MATH_PACKED_FP16 = 1u << 5
+  FSR1_FLAG_MATH_PACKED_FP16 = 1u << 5,
+  /* Diagnostics: never pick a shape-specialised kernel (e.g. the exact-2x variants, whose lanes own 2x2 output quads).
+   * The specialised kernels run the same per-pixel arithmetic on the same values: results are bit-identical either way
+   * (tests assert it); the flag exists so that this can be checked and the gain measured. */
+  FSR1_FLAG_NO_FAST_PATHS = 1u << 8
 };
 
 typedef enum fsr1_status {

@@ -409,3 +409,26 @@ def test_dispatches_are_graph_capturable(fsr):
     fsr.rcas(mid, eager, con=rc)
     torch.cuda.synchronize()
     assert torch.equal(out, eager)
+
+
+@pytest.mark.parametrize("shape", [(480, 270, 960, 540), (37, 23, 74, 46), (1, 1, 2, 2), (33, 9, 66, 18), (960, 540, 1920, 1080)],
+                         ids=lambda s: "%dx%d_to_%dx%d" % s)
+@pytest.mark.parametrize("fmt", ["f16", "f32", "rgba8"])
+def test_exact_2x_fast_path_is_bit_identical(fsr, shape, fmt):
+    """At exactly 2x (con0 = {1/2, 1/2, -1/4, -1/4}) the EASU kernel whose lanes own 2x2 output quads is selected (shifted
+    tiles); it must reproduce the generic kernel bit for bit (same per-pixel arithmetic on the same values), for both
+    arithmetics, incl. sizes that are / are not multiples of the tile and the 1x1 input."""
+    iw, ih, ow, oh = shape
+    img = frames.synthetic_frame(iw, ih, k=7, dtype=np.float32)
+    if fmt == "f16":
+        src, dt = dev(img.astype(np.float16)), torch.float16
+    elif fmt == "f32":
+        src, dt = dev(img), torch.float32
+    else:
+        src, dt = dev(np.floor(np.clip(img, 0, 1) * 255.0 + 0.5).astype(np.uint8)), torch.uint8
+    for flags in (0, fsr.FLAG_MATH_EXACT):
+        fast = torch.zeros(oh, ow, 4, dtype=dt, device="cuda")
+        slow = torch.zeros(oh, ow, 4, dtype=dt, device="cuda")
+        fsr.easu(src, fast, flags=flags)
+        fsr.easu(src, slow, flags=flags | fsr.FLAG_NO_FAST_PATHS)
+        assert torch.equal(fast, slow), "easu exact-2x path differs (flags %d)" % flags

@@ -11,7 +11,7 @@ parts=re.split(r"\n(_Z[\w]+):[^\n]*\n",txt)
 stats={}
 for i in range(1,len(parts),2):
     name,body=parts[i],parts[i+1]
-    body=body.split('s_endpgm')[0]
+    body=body.split('.Lfunc_end')[0]
     ins=[l.strip() for l in body.split('\n') if re.match(r'\s+[a-z]+_[a-z0-9_]+',l)]
     def c(p): return sum(1 for l in ins if re.match(p,l))
     stats[name]=(len(ins),c(r'v_'),c(r'v_(fma|mul|add|sub|fmac|mac)_f32'),c(r'v_pk_'),c(r'ds_'),c(r'(global|buffer|flat)_'),c(r's_waitcnt'),c(r'v_(rcp|rsq|sqrt)'))
