@@ -50,7 +50,7 @@ __global__ void __launch_bounds__(kThreads) easu_kernel(const EasuArgs a) {
   // ---- phase 3: output pixels; a lane owns a column, a wave 4 rows (S2: a lane owns a 2x2 quad, a wave 2 quad rows) ----
   const int lane = tid & 63, wave = tid >> 6;
   if constexpr (S2) {
-    static_assert(!COLOR && kTileW == 64 && kTileH % 8 == 0, "the exact-2x variant is built for the plain 64-wide tiles");
+    static_assert(!COLOR && kTileW == 64 && kTileH % 16 == 0, "the exact-2x variant is built for the plain 64-wide tiles");
     const int W = a.out.width, H = a.out.height;
     const bool hdr = (a.flags & FSR1_FLAG_HDR_SQUARE) != 0;
     struct __attribute__((aligned(sizeof(texel_t)))) pair_t { texel_t p[2]; };
