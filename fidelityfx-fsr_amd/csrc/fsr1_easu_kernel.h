@@ -22,6 +22,7 @@ size_t easu_lds_bytes(int fmt, int fp_w, int fp_h);
 template <int FMT, bool EXACT, bool COLOR = false, int FOUT = FMT, bool S2 = false>
 __global__ void __launch_bounds__(kThreads) easu_kernel(const EasuArgs a) {
   typedef typename Pixel<FOUT>::T texel_t;
+  constexpr bool kS2 = S2 && kTileH % 16 == 0;  // (other tile heights are tuning builds: the host never selects S2 for them)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   EasuLds l = easu_lds_carve(smem, a.fp_w * a.fp_h);
 
@@ -30,7 +31,7 @@ __global__ void __launch_bounds__(kThreads) easu_kernel(const EasuArgs a) {
   const int frame = t / tiles_per_frame;
   const int tf = t - frame * tiles_per_frame;
   const int ty = tf / a.tiles_x, tx = tf - ty * a.tiles_x;
-  const int ox0 = tx * kTileW - (S2 ? 1 : 0), oy0 = ty * kTileH - (S2 ? 1 : 0);
+  const int ox0 = tx * kTileW - (kS2 ? 1 : 0), oy0 = ty * kTileH - (kS2 ? 1 : 0);
 
   const float c0x = as_f32(a.con[0]), c0y = as_f32(a.con[1]), c0z = as_f32(a.con[2]), c0w = as_f32(a.con[3]);
 
@@ -49,8 +50,8 @@ __global__ void __launch_bounds__(kThreads) easu_kernel(const EasuArgs a) {
 
   // ---- phase 3: output pixels; a lane owns a column, a wave 4 rows (S2: a lane owns a 2x2 quad, a wave 2 quad rows) ----
   const int lane = tid & 63, wave = tid >> 6;
-  if constexpr (S2) {
-    static_assert(!COLOR && kTileW == 64 && kTileH % 16 == 0, "the exact-2x variant is built for the plain 64-wide tiles");
+  if constexpr (kS2) {
+    static_assert(!COLOR && kTileW == 64, "the exact-2x variant is built for the plain 64-wide tiles");
     const int W = a.out.width, H = a.out.height;
     const bool hdr = (a.flags & FSR1_FLAG_HDR_SQUARE) != 0;
     struct __attribute__((aligned(sizeof(texel_t)))) pair_t { texel_t p[2]; };
