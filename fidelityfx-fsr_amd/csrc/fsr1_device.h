@@ -124,6 +124,10 @@ __device__ __forceinline__ int xcd_swizzle(int b, int n) {
 // into v_fma_mixlo_f16 even with -ffp-contract=off, i.e. ONE rounding of the exact product to binary16
 // instead of the reference's binary32 product followed by the store's rounding.  The EXACT variants pin
 // the binary32 value first (costs no instruction).
+// `volatile` on purpose: clang then treats the statement as touching memory, which also stops it from merging the LDS
+// loads of consecutive pixels of one lane (the exact-2x EASU variant computes four pixels on the same 12-tap window).
+// Merged, the window stays live in ~50 more VGPRs: 96 instead of 53, 5 waves per SIMD instead of 8, and the kernel
+// takes 55.0 us instead of 48.7 us (capped at 64 VGPRs it spills: 87 us).  LDS bandwidth is not what EASU is short of.
 __device__ __forceinline__ float pinned(float x) { asm volatile("" : "+v"(x)); return x; }
 
 // RTNE float -> binary16 (v_cvt_f16_f32 under the default rounding mode; never cvt_pkrtz).
