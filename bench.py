@@ -34,6 +34,9 @@ WORKLOADS = {
     "1080p_to_4k": (1920, 1080, 3840, 2160, 1),          # BASELINE configs[1] (and [3] when --pipeline fused)
     "540p_to_1080p": (960, 540, 1920, 1080, 1),          # configs[0] shape
     "270p_to_540p": (480, 270, 960, 540, 1),             # a launch-bound size (see --graph)
+    "1440p_to_4k": (2560, 1440, 3840, 2160, 1),          # 1.5x "Quality", one frame
+    "1270p_to_4k": (2259, 1270, 3840, 2160, 1),          # 1.7x "Balanced" (PDF p.10 true-ratio shape)
+    "1662p_to_4k": (2954, 1662, 3840, 2160, 1),          # 1.3x "Ultra Quality"
     "1440p_to_4k_x8": (2560, 1440, 3840, 2160, 8),       # configs[2]: 64 frames over 8 GPUs
     "4k_to_8k_x16": (3840, 2160, 7680, 4320, 16),        # configs[4]: 128 frames over 8 GPUs
 }

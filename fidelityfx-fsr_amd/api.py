@@ -235,6 +235,8 @@ class FSR_Filter:
         self.fused = False
 
     def OnCreate(self, slowFallback=True, exact=False, fused=False):
+        """fused: False = EASU + RCAS dispatches, True = the single fused launch, "auto" = whichever is faster for the
+        scale (fsr1_params.fused = 2; the intermediary is still allocated so that either can run)."""
         _lib.load()
         self._flags = (FLAG_MATH_EXACT if exact else 0) if slowFallback else FLAG_MATH_PACKED_FP16
         self.fused = fused
@@ -250,7 +252,7 @@ class FSR_Filter:
         self._input, self._output, self._hdr = input, output, hdr
         # FSR_Filter.cpp:72-73 creates the EASU->RCAS intermediary at display size; here it has the
         # output's format (RGBA16F/RGBA32F) and batch size.
-        self.m_intermediary = None if self.fused else torch.empty_like(output)
+        self.m_intermediary = None if self.fused is True else torch.empty_like(output)
 
     def OnDestroyWindowSizeDependentResources(self):
         self.m_intermediary = None
@@ -267,7 +269,8 @@ class FSR_Filter:
             raise Fsr1Error("m_nUpscaleType == 0 (bilinear) is outside the EASU+RCAS path")
         hdr = self._hdr if hdr is None else hdr
         p = fsr1_params(float(pState.renderWidth), float(pState.renderHeight), int(bool(pState.bUseRcas)),
-                        float(pState.rcasAttenuation), int(bool(hdr)), int(self.fused and pState.bUseRcas), self._flags)
+                        float(pState.rcasAttenuation), int(bool(hdr)),
+                        (2 if self.fused == "auto" else int(bool(self.fused))) if pState.bUseRcas else 0, self._flags)
         i, o = image_of(self._input), image_of(self._output)
         if (o.width, o.height) != (displayWidth, displayHeight):
             raise Fsr1Error("display size changed: call OnCreateWindowSizeDependentResources again")

@@ -357,7 +357,16 @@ int fsr1_upscale_ex(const fsr1_image* in, const fsr1_image* intermediary, const 
   }
   FsrRcasCon(rcas_con, p->rcas_attenuation);  // :124
   const uint32_t rcas_flags = math | rcas_opts | (p->hdr ? FSR1_FLAG_HDR_SQUARE : 0u);  // :125 Sample.x = hdr
-  if (p->fused) return fsr1_easu_rcas_fused_dispatch_ex(in, out, easu_con, rcas_con, rcas_flags, stages, stream);
+  bool fused = p->fused == 1;
+  if (p->fused == 2) {  // auto: the fused kernel's apron and LDS footprint grow as the scale shrinks
+    float sx, sy;
+    memcpy(&sx, &easu_con[0], 4);
+    memcpy(&sy, &easu_con[1], 4);
+    fused = !intermediary || (sx <= 0.55f && sy <= 0.55f);
+  } else if (p->fused != 0 && p->fused != 1) {
+    return fail(FSR1_ERR_INVALID_ARGUMENT, "upscale: params.fused must be 0, 1 or 2 (auto)");
+  }
+  if (fused) return fsr1_easu_rcas_fused_dispatch_ex(in, out, easu_con, rcas_con, rcas_flags, stages, stream);
   if (!intermediary) return fail(FSR1_ERR_INVALID_ARGUMENT, "upscale: two-pass EASU+RCAS needs an intermediary image");
   // two dispatches: the prologue belongs to EASU's loads, the epilogue to RCAS's stores
   fsr1_color_stages pre, post;

@@ -11,7 +11,7 @@
  * data ever crosses a link.  Rank 0 prints one JSON line.
  *
  *   fsr1_runner [--gpus N] [--frames F] [--in WxH] [--out WxH] [--steps K] [--warmup W]
- *               [--pipeline two-pass|fused|easu] [--math f|exact] [--sharpness STOPS] [--hdr]
+ *               [--pipeline two-pass|fused|easu|auto] [--math f|exact] [--sharpness STOPS] [--hdr]
  *               [--stages BITS] [--grain AMOUNT]
  *
  * --stages fuses colour stages into the passes (FSR1_COLOR_* bits of fsr1_hip.h: 1 FsrSrtmF on the input, 2 FsrLfgaF
@@ -32,7 +32,7 @@
 
 typedef struct {
   int gpus, frames, in_w, in_h, out_w, out_h, steps, warmup, hdr;
-  int pipeline; /* 0 two-pass, 1 fused, 2 easu only */
+  int pipeline; /* 0 two-pass, 1 fused, 2 easu only, 3 auto (fsr1_params.fused = 2) */
   uint32_t math;
   float sharpness;
   uint32_t stages; /* FSR1_COLOR_* */
@@ -141,7 +141,7 @@ static void* worker(void* arg) {
   if (nf > 0) {
     HIP_OK(w, hipMalloc(&d_in, in_frame * nf));
     HIP_OK(w, hipMalloc(&d_out, out_frame * nf));
-    if (o->pipeline == 0) HIP_OK(w, hipMalloc(&d_mid, out_frame * nf));
+    if (o->pipeline == 0 || o->pipeline == 3) HIP_OK(w, hipMalloc(&d_mid, out_frame * nf));
     uint16_t* host = (uint16_t*)malloc(in_frame);
     if (!host) { snprintf(w->error, sizeof w->error, "out of host memory"); w->status = -1; return NULL; }
     for (int f = 0; f < nf; ++f) {
@@ -180,7 +180,7 @@ static void* worker(void* arg) {
   p.use_rcas = o->pipeline != 2;
   p.rcas_attenuation = o->sharpness;
   p.hdr = o->hdr;
-  p.fused = o->pipeline == 1;
+  p.fused = o->pipeline == 1 ? 1 : (o->pipeline == 3 ? 2 : 0);
   p.flags = o->math;
 
   hipEvent_t ev0, ev1;
@@ -188,11 +188,11 @@ static void* worker(void* arg) {
   HIP_OK(w, hipEventCreate(&ev1));
   float ms = 0.f;
   if (nf > 0) {
-    for (int i = 0; i < o->warmup; ++i) FSR_OK(w, fsr1_upscale_ex(&in, o->pipeline == 0 ? &mid : NULL, &out, &p, &stages, stream));
+    for (int i = 0; i < o->warmup; ++i) FSR_OK(w, fsr1_upscale_ex(&in, d_mid ? &mid : NULL, &out, &p, &stages, stream));
     HIP_OK(w, hipEventRecord(ev0, stream));
     for (int i = 0; i < o->steps; ++i) {
       stages.frame = (uint32_t)i; /* the grain / dither pattern changes every frame (ffx_fsr1.h:1006) */
-      FSR_OK(w, fsr1_upscale_ex(&in, o->pipeline == 0 ? &mid : NULL, &out, &p, &stages, stream));
+      FSR_OK(w, fsr1_upscale_ex(&in, d_mid ? &mid : NULL, &out, &p, &stages, stream));
     }
     HIP_OK(w, hipEventRecord(ev1, stream));
     HIP_OK(w, hipEventSynchronize(ev1));
@@ -222,7 +222,7 @@ static int parse_size(const char* s, int* w, int* h) { return sscanf(s, "%dx%d",
 
 static void usage(void) {
   puts("usage: fsr1_runner [--gpus N] [--frames F] [--in WxH] [--out WxH] [--steps K] [--warmup W]\n"
-       "                   [--pipeline two-pass|fused|easu] [--math f|exact] [--sharpness STOPS] [--hdr]\n"
+       "                   [--pipeline two-pass|fused|easu|auto] [--math f|exact] [--sharpness STOPS] [--hdr]\n"
        "                   [--stages BITS] [--grain AMOUNT]   (colour stages: 1 SRTM, 2 grain, 4 SRTM inverse, 8/16 TEPD 8/10-bit)\n"
        "defaults: 1 GPU, 1 frame per GPU, 1920x1080 -> 3840x2160, 100 steps, 10 warmup, two-pass, f, 0.25 stops");
 }
@@ -246,6 +246,7 @@ int main(int argc, char** argv) {
     else if (!strcmp(a, "--out")) { if (!parse_size(v, &o.out_w, &o.out_h)) { fprintf(stderr, "bad --out %s\n", v); return 2; } ++i; }
     else if (!strcmp(a, "--pipeline")) {
       if (!strcmp(v, "two-pass")) o.pipeline = 0; else if (!strcmp(v, "fused")) o.pipeline = 1; else if (!strcmp(v, "easu")) o.pipeline = 2;
+      else if (!strcmp(v, "auto")) o.pipeline = 3;
       else { fprintf(stderr, "bad --pipeline %s\n", v); return 2; }
       ++i;
     } else if (!strcmp(a, "--math")) {
@@ -290,7 +291,7 @@ int main(int argc, char** argv) {
            "\"steps\": %d, \"seconds\": %.6f, \"in\": \"%dx%d\", \"out\": \"%dx%d\", \"pipeline\": \"%s\", \"math\": \"%s\", \"color_stages\": %u, "
            "\"algorithmic_GBps\": %.1f, \"hbm_peak_frac\": %.4f, \"per_gpu_ms\": [",
            (double)pixels / sec / 1e6, o.gpus, (unsigned long long)frames, o.steps, sec, o.in_w, o.in_h, o.out_w, o.out_h,
-           o.pipeline == 0 ? "two-pass" : (o.pipeline == 1 ? "fused" : "easu"), o.math ? "exact" : "f", o.stages, bytes / sec / 1e9,
+           o.pipeline == 0 ? "two-pass" : (o.pipeline == 1 ? "fused" : (o.pipeline == 2 ? "easu" : "auto")), o.math ? "exact" : "f", o.stages, bytes / sec / 1e9,
            bytes / sec / 1e9 / (8000.0 * o.gpus));
     for (int i = 0; i < o.gpus; ++i) printf("%s%.3f", i ? ", " : "", (double)gathered[3 * i + 2] * 1e-6);
     printf("]}\n");

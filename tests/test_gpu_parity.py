@@ -432,3 +432,22 @@ def test_exact_2x_fast_path_is_bit_identical(fsr, shape, fmt):
         fsr.easu(src, fast, flags=flags)
         fsr.easu(src, slow, flags=flags | fsr.FLAG_NO_FAST_PATHS)
         assert torch.equal(fast, slow), "easu exact-2x path differs (flags %d)" % flags
+
+
+def test_upscale_auto_pipeline(fsr, port):
+    """fsr1_params.fused = 2 picks the fused launch at 2x and the two dispatches at 1.5x; the image is the same either way
+    (fused == two-pass bit for bit), so only the choice itself needs checking: the intermediary is written iff two-pass ran."""
+    for (iw, ih, ow, oh), expect_two_pass in (((160, 90, 320, 180), False), ((160, 90, 240, 135), True)):
+        src = dev(frames.synthetic_frame(iw, ih, k=2, dtype=np.float16))
+        dst = torch.zeros(oh, ow, 4, dtype=torch.float16, device="cuda")
+        filt = fsr.FSR_Filter()
+        filt.OnCreate(slowFallback=True, exact=True, fused="auto")
+        filt.OnCreateWindowSizeDependentResources(src, dst, ow, oh)
+        filt.m_intermediary.fill_(-1.0)
+        filt.Upscale(ow, oh, fsr.State(iw, ih, bUseRcas=True, rcasAttenuation=0.25))
+        touched = bool((host(filt.m_intermediary) != -1.0).any())
+        assert touched == expect_two_pass
+        con = port.FsrEasuCon(iw, ih, iw, ih, ow, oh)
+        mid = port.easu_f(host(src).astype(np.float32), ow, oh, con).astype(np.float16).astype(np.float32)
+        assert_exact16(host(dst), port.rcas_f(mid, port.FsrRcasCon(0.25)), "auto pipeline")
+        filt.OnDestroy()

@@ -26,7 +26,7 @@ def test_runner_builds_and_parses_arguments(runner):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("pipeline", ["two-pass", "fused", "easu"])
+@pytest.mark.parametrize("pipeline", ["two-pass", "fused", "easu", "auto"])
 def test_runner_on_gpu(runner, pipeline):
     out = subprocess.run([runner, "--gpus", "1", "--frames", "3", "--in", "640x360", "--out", "1280x720", "--steps", "20",
                           "--warmup", "3", "--pipeline", pipeline], capture_output=True, text=True, timeout=300)
