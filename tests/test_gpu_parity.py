@@ -451,3 +451,22 @@ def test_upscale_auto_pipeline(fsr, port):
         mid = port.easu_f(host(src).astype(np.float32), ow, oh, con).astype(np.float16).astype(np.float32)
         assert_exact16(host(dst), port.rcas_f(mid, port.FsrRcasCon(0.25)), "auto pipeline")
         filt.OnDestroy()
+
+
+def test_exact_2x_fast_path_batch_and_pitches(fsr):
+    """The exact-2x EASU variant on a batch with padded rows and frames (views into larger allocations), HDR square on."""
+    n, iw, ih = 3, 70, 37
+    ow, oh = 2 * iw, 2 * ih
+    big_in = torch.zeros(n, ih + 3, iw + 5, 4, dtype=torch.float16, device="cuda")
+    src = big_in[:, :ih, :iw]
+    for f in range(n):
+        src[f].copy_(dev(frames.synthetic_frame(iw, ih, k=10 + f, dtype=np.float16)))
+    outs = []
+    for flags in (fsr.FLAG_HDR_SQUARE, fsr.FLAG_HDR_SQUARE | fsr.FLAG_NO_FAST_PATHS):
+        big_out = torch.full((n, oh + 2, ow + 6, 4), -3.0, dtype=torch.float16, device="cuda")
+        dst = big_out[:, :oh, :ow]
+        fsr.easu(src, dst, flags=flags)
+        torch.cuda.synchronize()
+        assert float((big_out[:, oh:] != -3.0).sum()) == 0 and float((big_out[:, :, ow:] != -3.0).sum()) == 0  # padding untouched
+        outs.append(dst.clone())
+    assert torch.equal(outs[0], outs[1])
