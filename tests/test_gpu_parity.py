@@ -470,3 +470,61 @@ def test_exact_2x_fast_path_batch_and_pitches(fsr):
         assert float((big_out[:, oh:] != -3.0).sum()) == 0 and float((big_out[:, :, ow:] != -3.0).sum()) == 0  # padding untouched
         outs.append(dst.clone())
     assert torch.equal(outs[0], outs[1])
+
+
+def test_random_shapes_sweep(fsr, port):
+    """Seeded sweep over random sizes, ratios (0.35x .. 4.3x per axis, also anisotropic), dynamic-resolution viewports
+    and offsets, formats and flags, small enough for the CPU oracle: EXACT arithmetic must be bit-identical, the fused
+    launch must equal the two dispatches, the default arithmetic stays within 1 binary16 ULP."""
+    rng = np.random.default_rng(20260922)
+    cases = 0
+    for it in range(48):
+        iw, ih = int(rng.integers(1, 90)), int(rng.integers(1, 60))
+        kind = it % 4
+        if kind == 0:    # exact 2x (fast path)
+            ow, oh = 2 * iw, 2 * ih
+        elif kind == 1:  # up to ~4.3x
+            ow, oh = int(iw * rng.uniform(1.0, 4.3)) + 1, int(ih * rng.uniform(1.0, 4.3)) + 1
+        elif kind == 2:  # anisotropic / slight minification
+            ow, oh = max(1, int(iw * rng.uniform(0.5, 3.0))), max(1, int(ih * rng.uniform(0.35, 2.0)))
+        else:            # viewport inside a larger resource + offset
+            ow, oh = int(iw * rng.uniform(1.0, 2.5)) + 1, int(ih * rng.uniform(1.0, 2.5)) + 1
+        img = frames.synthetic_frame(iw, ih, k=it, dtype=np.float32)
+        img[rng.integers(0, ih), rng.integers(0, iw), :3] = 0.0
+        img[rng.integers(0, ih), rng.integers(0, iw), :3] = 1.0
+        if kind == 3 and iw > 4 and ih > 4:
+            vw, vh = int(rng.integers(2, iw)), int(rng.integers(2, ih))
+            offx, offy = float(rng.integers(0, iw - vw + 1)), float(rng.integers(0, ih - vh + 1))
+            con = port.FsrEasuConOffset(vw, vh, iw, ih, ow, oh, offx, offy)
+        else:
+            con = port.FsrEasuCon(iw, ih, iw, ih, ow, oh)
+        stops = float(rng.choice([0.0, 0.25, 1.0, 2.0]))
+        rcon = port.FsrRcasCon(stops)
+        rflag = int(rng.choice([0, fsr.FLAG_RCAS_DENOISE, fsr.FLAG_RCAS_PASSTHROUGH_ALPHA, fsr.FLAG_HDR_SQUARE]))
+        oflag = {0: 0, fsr.FLAG_RCAS_DENOISE: 1, fsr.FLAG_RCAS_PASSTHROUGH_ALPHA: 2, fsr.FLAG_HDR_SQUARE: 4}[rflag]
+        f16 = bool(it % 3)
+        src = dev(img.astype(np.float16) if f16 else img)
+        dt = torch.float16 if f16 else torch.float32
+        img_in = host(src).astype(np.float32)
+        want_mid = port.easu_f(img_in, ow, oh, con)
+        for exact in (True, False):
+            fl = fsr.FLAG_MATH_EXACT if exact else 0
+            mid = torch.zeros(oh, ow, 4, dtype=dt, device="cuda")
+            out = torch.zeros_like(mid)
+            fus = torch.zeros_like(mid)
+            fsr.easu(src, mid, con=con, flags=fl)
+            fsr.rcas(mid, out, con=rcon, flags=fl | rflag)
+            fsr.easu_rcas_fused(src, fus, easu_con=con, rcas_con=rcon, flags=fl | rflag)
+            got_mid, got_out = host(mid), host(out)
+            what = "case %d %dx%d->%dx%d kind %d %s" % (it, iw, ih, ow, oh, kind, "exact" if exact else "f")
+            assert torch.equal(out, fus), what + ": fused != two-pass"
+            want_out = port.rcas_f(got_mid.astype(np.float32), rcon, oflag)
+            if exact:
+                (assert_exact16 if f16 else assert_exact32)(got_mid, want_mid, what + " easu")
+                (assert_exact16 if f16 else assert_exact32)(got_out, want_out, what + " rcas")
+            else:
+                import cpu_oracle
+                assert cpu_oracle.half_ulp_diff(got_mid.astype(np.float32), want_mid).max() <= 1, what + " easu"
+                assert cpu_oracle.half_ulp_diff(got_out.astype(np.float32), want_out).max() <= 1, what + " rcas"
+            cases += 1
+    assert cases == 96

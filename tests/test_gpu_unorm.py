@@ -120,3 +120,43 @@ def test_unorm_codes_roundtrip_through_constant_image(fsr):
         m, d = mid.cpu().numpy(), dst.cpu().numpy()
         assert (m[..., :3] == code).all() and (m[..., 3] == 255).all(), code
         assert (d[2:-2, 2:-2, :3] == code).all(), code  # interior: the image edge sees RCAS's zero loads
+
+
+def test_unorm_random_shapes_sweep(fsr, port):
+    """Seeded sweep over random sizes / ratios for both 32 bpp formats, EXACT arithmetic: every code of EASU, of RCAS (on the
+    GPU's own intermediary) and of the fused launch equals the oracle pipeline's."""
+    rng = np.random.default_rng(7)
+    for it in range(16):
+        iw, ih = int(rng.integers(1, 80)), int(rng.integers(1, 50))
+        if it % 2:
+            ow, oh = 2 * iw, 2 * ih
+        else:
+            ow, oh = int(iw * rng.uniform(1.0, 3.0)) + 1, int(ih * rng.uniform(1.0, 3.0)) + 1
+        img = frames.synthetic_frame(iw, ih, k=it, dtype=np.float32)
+        con = port.FsrEasuCon(iw, ih, iw, ih, ow, oh)
+        rcon = port.FsrRcasCon(0.25)
+        fl = fsr.FLAG_MATH_EXACT
+        if it % 4 < 2:
+            codes = encode(img, 255).astype(np.uint8)
+            src = torch.from_numpy(codes).cuda()
+            mk = lambda: torch.zeros(oh, ow, 4, dtype=torch.uint8, device="cuda")
+            dec = lambda c: decode(c, 255)
+            enc = lambda x: encode(x, 255)
+            get = lambda t: t.cpu().numpy()
+        else:
+            img[..., 3] = 1.0
+            words = pack10(img)
+            src = torch.from_numpy(words.view(np.int32)).cuda()
+            mk = lambda: torch.zeros(oh, ow, dtype=torch.int32, device="cuda")
+            dec, enc = unpack10, pack10
+            get = lambda t: t.cpu().numpy().view(np.uint32)
+            codes = words
+        mid, out, fus = mk(), mk(), mk()
+        fsr.easu(src, mid, con=con, flags=fl)
+        fsr.rcas(mid, out, con=rcon, flags=fl)
+        fsr.easu_rcas_fused(src, fus, easu_con=con, rcas_con=rcon, flags=fl)
+        torch.cuda.synchronize()
+        what = "case %d %dx%d->%dx%d" % (it, iw, ih, ow, oh)
+        assert np.array_equal(get(mid), enc(port.easu_f(dec(codes), ow, oh, con))), what + " easu"
+        assert np.array_equal(get(out), enc(port.rcas_f(dec(get(mid)), rcon))), what + " rcas"
+        assert np.array_equal(get(fus), get(out)), what + " fused"
