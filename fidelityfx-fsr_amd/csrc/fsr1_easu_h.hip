@@ -8,9 +8,11 @@
 // reference's own H path is not (different magic constants 0x7784/0x59a3, true rcp in FsrEasuSetH).
 //
 // Same work decomposition as the fp32 kernel (fsr1_easu.hip): 64x16 output tile per 256-thread
-// workgroup, footprint staged once into LDS with clamp-to-edge applied; the LDS texel is
-// (R, G, B, luma) in binary16 (8 bytes), luma = B*0.5 + (R*0.5 + G) evaluated once per input texel
-// (:535-538 — it depends on the texel only).  Position arithmetic stays fp32 as in the reference (:513-516).
+// workgroup, footprint staged once into LDS with clamp-to-edge applied, and everything FsrEasuH recomputes per
+// output pixel although it depends on the input only — luma (:535-538), the per-position terms of FsrEasuSetH
+// (:486-502), the (-x, x) min/max pairs of the 2x2 block (:575-577) — evaluated once per input texel, as the very
+// binary16 operation sequences the reference runs per lane.  Texel channels are kept as (texel, right neighbour)
+// half2 pairs, the operand shape of the two-taps-per-op FsrEasuTapH.  Position arithmetic stays fp32 (:513-516).
 #include "fsr1_device.h"
 
 namespace fsr1 {
@@ -81,9 +83,32 @@ __device__ __forceinline__ void easu_tap_h(EasuHTaps& p, half2_t offX, half2_t o
   p.pW = p.pW + w;
 }
 
+// LDS per footprint texel (48 bytes, the same budget as the fp32 kernel):
+//   tex1  half4  R G B luma of the texel                                   (phase 1; luma = B*0.5 + (R*0.5 + G), :535-538)
+//   texP  4 x half2  (R,G,B,luma) paired with the texel to the right       -> one ds_read_b128 per two-tap FsrEasuTapH call
+//   ana1  half4  dirX dirY lenX lenY of FsrEasuSetH for the '+' around the texel (:476-503: they do not depend on the
+//                output pixel, only their bilinear weights do), each a single binary16 operation sequence in the
+//                reference's order, so the per-pixel accumulation that follows sees bit-identical operands
+//   both  3 x half2  (max of -x, max of x) over the 2x2 block at the texel, per channel (:575-577)
+struct EasuHLds {
+  half4_t* tex1;
+  uint4* texP;
+  half4_t* ana1;
+  uint4* both;
+};
+
+__device__ __forceinline__ half2_t as_h2(uint32_t u) { return __builtin_bit_cast(half2_t, u); }
+__device__ __forceinline__ uint32_t as_u(half2_t h) { return __builtin_bit_cast(uint32_t, h); }
+__device__ __forceinline__ half2_t swap2(half2_t a) { return __builtin_shufflevector(a, a, 1, 0); }
+
 __global__ void __launch_bounds__(kThreads) easu_h_kernel(const EasuArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  half4_t* const tex = reinterpret_cast<half4_t*>(smem);  // [fh][fw] R G B luma
+  const int cap = a.fp_w * a.fp_h;
+  EasuHLds l;
+  l.texP = reinterpret_cast<uint4*>(smem);
+  l.both = reinterpret_cast<uint4*>(smem + (size_t)cap * 16);
+  l.tex1 = reinterpret_cast<half4_t*>(smem + (size_t)cap * 32);
+  l.ana1 = reinterpret_cast<half4_t*>(smem + (size_t)cap * 40);
 
   const int tiles_per_frame = a.tiles_x * a.tiles_y;
   const int t = xcd_swizzle(blockIdx.x, tiles_per_frame * a.frames);
@@ -100,9 +125,10 @@ __global__ void __launch_bounds__(kThreads) easu_h_kernel(const EasuArgs a) {
   const int fh = min((int)floorf((float)oyl * c0y + c0w) + 2 - fy0 + 1, a.fp_h);
 
   const int tid = threadIdx.x;
-  {
+  const int n = fw * fh;
+  const half_t one = (half_t)1.0f, zero = (half_t)0.0f;
+  {  // ---- phase 1: HBM -> LDS (clamp-to-edge applied), luma once per input texel ----
     const char* const in_frame = a.in.base + (long long)frame * a.in.frame_stride;
-    const int n = fw * fh;
     const float inv_fw = 1.0f / (float)fw;
     for (int i = tid; i < n; i += kThreads) {
       const int ly = (int)(((float)i + 0.5f) * inv_fw);
@@ -111,8 +137,33 @@ __global__ void __launch_bounds__(kThreads) easu_h_kernel(const EasuArgs a) {
       const int gx = min(max(fx0 + lx, 0), a.in.width - 1);
       const half4_t c = *reinterpret_cast<const half4_t*>(in_frame + (long long)gy * a.in.pitch + (size_t)gx * sizeof(half4_t));
       const half_t hlf = (half_t)0.5f;
-      tex[i] = half4_t{c.x, c.y, c.z, (half_t)(c.z * hlf + (c.x * hlf + c.y))};  // :535-538
+      l.tex1[i] = half4_t{c.x, c.y, c.z, (half_t)(c.z * hlf + (c.x * hlf + c.y))};  // :535-538
     }
+  }
+  __syncthreads();
+  // ---- phase 2: per-texel terms (border texels read clamped neighbours and produce values nobody uses) ----
+  for (int i = tid; i < n; i += kThreads) {
+    const int iu = max(i - fw, 0), id = min(i + fw, n - 1), il = max(i - 1, 0), ir = min(i + 1, n - 1), idr = min(id + 1, n - 1);
+    const half4_t tc = l.tex1[i], tr = l.tex1[ir], td = l.tex1[id], tdr = l.tex1[idr];
+    const half_t lA = l.tex1[iu].w, lB = l.tex1[il].w, lC = tc.w, lD = tr.w, lE = td.w;
+    // FsrEasuSetH :486-502, one AH2 lane
+    const half_t dc = lD - lC, cb = lC - lB;
+    half_t lenX = hrcp1(hmax1(habs1(dc), habs1(cb)));
+    const half_t dirX = lD - lB;
+    lenX = hmin1(hmax1(habs1(dirX) * lenX, zero), one);
+    lenX = lenX * lenX;
+    const half_t ec = lE - lC, ca = lC - lA;
+    half_t lenY = hrcp1(hmax1(habs1(ec), habs1(ca)));
+    const half_t dirY = lE - lA;
+    lenY = hmin1(hmax1(habs1(dirY) * lenY, zero), one);
+    lenY = lenY * lenY;
+    l.ana1[i] = half4_t{dirX, dirY, lenX, lenY};
+    l.texP[i] = uint4{as_u(h2(tc.x, tr.x)), as_u(h2(tc.y, tr.y)), as_u(h2(tc.z, tr.z)), as_u(h2(tc.w, tr.w))};
+    // :575-577 min and max of the 2x2 block f g / j k through max() of (-x, x) pairs
+    const half2_t bR = hmax2(hmax2(h2(-tc.x, tc.x), h2(-tr.x, tr.x)), hmax2(h2(-td.x, td.x), h2(-tdr.x, tdr.x)));
+    const half2_t bG = hmax2(hmax2(h2(-tc.y, tc.y), h2(-tr.y, tr.y)), hmax2(h2(-td.y, td.y), h2(-tdr.y, tdr.y)));
+    const half2_t bB = hmax2(hmax2(h2(-tc.z, tc.z), h2(-tr.z, tr.z)), hmax2(h2(-td.z, td.z), h2(-tdr.z, tdr.z)));
+    l.both[i] = uint4{as_u(bR), as_u(bG), as_u(bB), 0u};
   }
   __syncthreads();
 
@@ -125,7 +176,6 @@ __global__ void __launch_bounds__(kThreads) easu_h_kernel(const EasuArgs a) {
   ppx -= fpx;
   const int lx = (int)fpx - fx0;
   const bool hdr = (a.flags & FSR1_FLAG_HDR_SQUARE) != 0;
-  const half_t one = (half_t)1.0f, zero = (half_t)0.0f;
 
 #pragma unroll 1
   for (int r = 0; r < kTileH / 4; ++r) {
@@ -135,21 +185,24 @@ __global__ void __launch_bounds__(kThreads) easu_h_kernel(const EasuArgs a) {
     const float fpy = floorf(ppy);
     ppy -= fpy;
     const half2_t ppp = h2((half_t)ppx, (half_t)ppy);  // :516 AH2(pp), RTNE
-    const half4_t* const f = tex + ((int)fpy - fy0) * fw + lx;
+    const int f = ((int)fpy - fy0) * fw + lx;            // footprint index of texel 'f'
     //    b c
     //  e f g h
     //  i j k l
     //    n o
-    const half4_t tb = f[-fw], tc = f[-fw + 1];
-    const half4_t te = f[-1], tF = f[0], tg = f[1], th = f[2];
-    const half4_t ti = f[fw - 1], tj = f[fw], tk = f[fw + 1], tl = f[fw + 2];
-    const half4_t tn = f[2 * fw], to = f[2 * fw + 1];
-
-    // :552-558
-    EasuHAcc s = {h2s(zero), h2s(zero), h2s(zero)};
+    // :552-558 the two FsrEasuSetH calls: lanes (f, g) with weights w1, lanes (j, k) with weights w2
     const half2_t wx = h2(one, zero) + h2(-ppp.x, ppp.x);  // :483-484
-    easu_set_h(s, wx * h2s(one - ppp.y), h2(tb.w, tc.w), h2(te.w, tF.w), h2(tF.w, tg.w), h2(tg.w, th.w), h2(tj.w, tk.w));
-    easu_set_h(s, wx * h2s(ppp.y), h2(tF.w, tg.w), h2(ti.w, tj.w), h2(tj.w, tk.w), h2(tk.w, tl.w), h2(tn.w, to.w));
+    const half2_t w1 = wx * h2s(one - ppp.y), w2 = wx * h2s(ppp.y);
+    const half4_t af = l.ana1[f], ag = l.ana1[f + 1], aj = l.ana1[f + fw], ak = l.ana1[f + fw + 1];
+    EasuHAcc s = {h2s(zero), h2s(zero), h2s(zero)};
+    s.dirPX = s.dirPX + h2(af.x, ag.x) * w1;
+    s.lenP = s.lenP + h2(af.z, ag.z) * w1;
+    s.dirPY = s.dirPY + h2(af.y, ag.y) * w1;
+    s.lenP = s.lenP + h2(af.w, ag.w) * w1;
+    s.dirPX = s.dirPX + h2(aj.x, ak.x) * w2;
+    s.lenP = s.lenP + h2(aj.z, ak.z) * w2;
+    s.dirPY = s.dirPY + h2(aj.y, ak.y) * w2;
+    s.lenP = s.lenP + h2(aj.w, ak.w) * w2;
     half2_t dir = h2(s.dirPX.x + s.dirPX.y, s.dirPY.x + s.dirPY.y);
     half_t len = s.lenP.x + s.lenP.y;
     // :560-572
@@ -166,22 +219,22 @@ __global__ void __launch_bounds__(kThreads) easu_h_kernel(const EasuArgs a) {
     const half2_t len2 = h2(one + (stretch - one) * len, one + (half_t)-0.5f * len);
     const half_t lob = (half_t)0.5f + (half_t)((1.0 / 4.0 - 0.04) - 0.5) * len;
     const half_t clp = APrxLoRcpH1(lob);
-    // :575-577 min and max of f,g,j,k through max() of (-x, x) pairs
-    const half2_t bothR = hmax2(hmax2(h2(-tF.x, tF.x), h2(-tg.x, tg.x)), hmax2(h2(-tj.x, tj.x), h2(-tk.x, tk.x)));
-    const half2_t bothG = hmax2(hmax2(h2(-tF.y, tF.y), h2(-tg.y, tg.y)), hmax2(h2(-tj.y, tj.y), h2(-tk.y, tk.y)));
-    const half2_t bothB = hmax2(hmax2(h2(-tF.z, tF.z), h2(-tg.z, tg.z)), hmax2(h2(-tj.z, tj.z), h2(-tk.z, tk.z)));
-    // :579-588 pairs in the reference's order: bc, ij, fe, kl, hg, on
+    // :579-588 pairs in the reference's order: bc, ij, fe, kl, hg, on.  texP[t] holds (t, t+1), so bc / ij / kl come as
+    // stored and fe / hg / on are the swapped (e,f) / (g,h) / (n,o)
     EasuHTaps p = {h2s(zero), h2s(zero), h2s(zero), h2s(zero)};
     const half2_t px2 = h2s(ppp.x), py2 = h2s(ppp.y);
-    easu_tap_h(p, h2(zero, one) - px2, h2(-one, -one) - py2, dir, len2, lob, clp, h2(tb.x, tc.x), h2(tb.y, tc.y), h2(tb.z, tc.z));
-    easu_tap_h(p, h2(-one, zero) - px2, h2(one, one) - py2, dir, len2, lob, clp, h2(ti.x, tj.x), h2(ti.y, tj.y), h2(ti.z, tj.z));
-    easu_tap_h(p, h2(zero, -one) - px2, h2(zero, zero) - py2, dir, len2, lob, clp, h2(tF.x, te.x), h2(tF.y, te.y), h2(tF.z, te.z));
-    easu_tap_h(p, h2(one, (half_t)2.0f) - px2, h2(one, one) - py2, dir, len2, lob, clp, h2(tk.x, tl.x), h2(tk.y, tl.y), h2(tk.z, tl.z));
-    easu_tap_h(p, h2((half_t)2.0f, one) - px2, h2(zero, zero) - py2, dir, len2, lob, clp, h2(th.x, tg.x), h2(th.y, tg.y), h2(th.z, tg.z));
-    easu_tap_h(p, h2(one, zero) - px2, h2((half_t)2.0f, (half_t)2.0f) - py2, dir, len2, lob, clp, h2(to.x, tn.x), h2(to.y, tn.y), h2(to.z, tn.z));
+    const uint4 bc = l.texP[f - fw], ij = l.texP[f + fw - 1], ef = l.texP[f - 1], kl = l.texP[f + fw + 1], gh = l.texP[f + 1], no = l.texP[f + 2 * fw];
+    easu_tap_h(p, h2(zero, one) - px2, h2(-one, -one) - py2, dir, len2, lob, clp, as_h2(bc.x), as_h2(bc.y), as_h2(bc.z));
+    easu_tap_h(p, h2(-one, zero) - px2, h2(one, one) - py2, dir, len2, lob, clp, as_h2(ij.x), as_h2(ij.y), as_h2(ij.z));
+    easu_tap_h(p, h2(zero, -one) - px2, h2(zero, zero) - py2, dir, len2, lob, clp, swap2(as_h2(ef.x)), swap2(as_h2(ef.y)), swap2(as_h2(ef.z)));
+    easu_tap_h(p, h2(one, (half_t)2.0f) - px2, h2(one, one) - py2, dir, len2, lob, clp, as_h2(kl.x), as_h2(kl.y), as_h2(kl.z));
+    easu_tap_h(p, h2((half_t)2.0f, one) - px2, h2(zero, zero) - py2, dir, len2, lob, clp, swap2(as_h2(gh.x)), swap2(as_h2(gh.y)), swap2(as_h2(gh.z)));
+    easu_tap_h(p, h2(one, zero) - px2, h2((half_t)2.0f, (half_t)2.0f) - py2, dir, len2, lob, clp, swap2(as_h2(no.x)), swap2(as_h2(no.y)), swap2(as_h2(no.z)));
     const half_t aR = p.pR.x + p.pR.y, aG = p.pG.x + p.pG.y, aB = p.pB.x + p.pB.y;
     const half_t aW = p.pW.x + p.pW.y;
     // :593
+    const uint4 bo = l.both[f];
+    const half2_t bothR = as_h2(bo.x), bothG = as_h2(bo.y), bothB = as_h2(bo.z);
     const half_t rW = hrcp1(aW);
     half_t pr = hmin1(bothR.y, hmax1(-bothR.x, aR * rW));
     half_t pg = hmin1(bothG.y, hmax1(-bothG.x, aG * rW));
@@ -191,7 +244,7 @@ __global__ void __launch_bounds__(kThreads) easu_h_kernel(const EasuArgs a) {
   }
 }
 
-size_t easu_h_lds_bytes(int fp_w, int fp_h) { return (size_t)fp_w * fp_h * sizeof(half4_t); }
+size_t easu_h_lds_bytes(int fp_w, int fp_h) { return (size_t)fp_w * fp_h * 48; }
 
 hipError_t easu_h_launch(const EasuArgs& a, hipStream_t stream) {
   const dim3 grid((unsigned)(a.tiles_x * a.tiles_y * a.frames)), block(kThreads);
