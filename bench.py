@@ -28,6 +28,10 @@ HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/
 # VALU issue peak: 256 CUs x 4 SIMDs, one wave64 fp32 instruction per 2 cycles at 2.4 GHz (MI355X_MICROARCH.md:
 # "v_fma_f32 (wave64) 2 cyc (SIMD-32)") = 1228.8 G wave-instructions/s = 157.3 TFLOP/s of fp32 FMA
 VALU_PEAK_GINST = 256 * 4 * 2.4 / 2.0
+# BASELINE.md §1 (docs/FidelityFX-FSR-Overview-Integration.pdf p.9): "FSR performance overhead" — EASU + RCAS, FP16 path —
+# at a 4K target is <= 0.40 ms on the fastest tier the reference measured (RX 6800 XT / RTX 3080), for all four presets,
+# i.e. >= 20 700 upscaled Mpix/s.  The only published figure for this metric: an upper bound on time, on other hardware.
+PUBLISHED_4K_MPIX_S = 3840 * 2160 / 0.40e-3 / 1e6
 
 WORKLOADS = {
     # name: (in_w, in_h, out_w, out_h, frames per step per GPU)
@@ -330,7 +334,10 @@ def main():
                 args.pipeline, "upscaled megapixels/sec (EASU+RCAS, 1080p->4K fp16)"),
             "value": round(value, 1), "unit": "Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(total["seconds"] * 1e3 / args.steps, 5), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32" if args.math != "h" else "f16", "data": "synthetic",
+            "vs_baseline": round(value / world / PUBLISHED_4K_MPIX_S, 2) if (out_w, out_h) == (3840, 2160) and args.pipeline in ("two-pass", "fused") and not args.stages else None,
+            "vs_baseline_ref": "per GPU, vs BASELINE.md §1: EASU+RCAS <= 0.40 ms per 4K frame on RX 6800 XT / RTX 3080 (reference PDF p.9) = >= 20736 Mpix/s; "
+                               "an upper bound on time, measured on other hardware",
+            "dtype": "f32" if args.math != "h" else "f16", "data": "synthetic",
             "config": {"workload": "%s: %dx%d -> %dx%d %s, %d frame(s)/step/GPU, %s, math=%s, ring of %d frame sets"
                                    % (args.workload, in_w, in_h, out_w, out_h, args.storage.upper(), frames, args.pipeline, args.math, ring),
                        "pipeline": args.pipeline, "storage": args.storage, "color_stages": args.stages, "hip_graph_steps": args.graph, "rcas_sharpness_stops": 0.25,
