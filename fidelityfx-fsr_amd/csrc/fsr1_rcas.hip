@@ -40,7 +40,13 @@ void rcas_geometry(int width, int height, int frames, int* tiles_x, int* tiles_y
 hipError_t rcas_launch(const RcasArgs& a, int fmt, bool exact, hipStream_t stream) {
   const dim3 grid((unsigned)(a.tiles_x * a.tiles_y * a.frames)), block(kRcasThreads);
   const bool opts = (a.flags & (FSR1_FLAG_RCAS_DENOISE | FSR1_FLAG_RCAS_PASSTHROUGH_ALPHA | FSR1_FLAG_HDR_SQUARE)) != 0;
-#define FSR1_RCAS(F, E, O) hipLaunchKernelGGL((rcas_kernel<F, E, O, false, F>), grid, block, 0, stream, a)
+  // shallow ring when the image is short of waves: fewer than 6 per SIMD in 16-row strips (RGBA32F: always 4 rows)
+  const bool shallow = (long long)a.tiles_x * ((a.in.height + 15) / 16) * a.frames * kRcasWaves < 6LL * 4 * 256;
+#define FSR1_RCAS(F, E, O)                                                                                                                  \
+  do {                                                                                                                                      \
+    if (shallow) hipLaunchKernelGGL((rcas_kernel<F, E, O, false, F, (F == FSR1_FORMAT_RGBA32F ? 4 : 2)>), grid, block, 0, stream, a);       \
+    else hipLaunchKernelGGL((rcas_kernel<F, E, O, false, F, (F == FSR1_FORMAT_RGBA32F ? 4 : kRcasRing)>), grid, block, 0, stream, a);       \
+  } while (0)
 #define FSR1_RCAS_O(F, E) do { if (opts) FSR1_RCAS(F, E, true); else FSR1_RCAS(F, E, false); } while (0)
 #define FSR1_RCAS_E(F) do { if (exact) FSR1_RCAS_O(F, true); else FSR1_RCAS_O(F, false); } while (0)
   switch (fmt) {

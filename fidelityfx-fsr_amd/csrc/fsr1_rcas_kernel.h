@@ -34,7 +34,7 @@ template <> struct RcasPair<FSR1_FORMAT_R10G10B10A2_UNORM> { typedef uint32_t T 
 // image, so nothing is predicated except the apron load of lanes 0 / 63.
 // COLOR: colour stages fused in (fsr1_color_math.h) — FsrSrtmF on every tap as it is loaded (the role of the
 // FsrRcasInputF callback, ffx_fsr1.h:682), FsrLfgaF / FsrSrtmInvF / FsrTepdC*F on the result before it is stored as FOUT.
-template <int FMT, bool EXACT, bool OPTS, bool INTERIOR, bool COLOR, int FOUT>
+template <int FMT, bool EXACT, bool OPTS, bool INTERIOR, bool COLOR, int FOUT, int RING>
 __device__ __forceinline__ void rcas_strip(const RcasArgs& a, int frame, int x0, int y0, int lane) {
   typedef typename Pixel<FMT>::T texel_t;
   typedef typename RcasPair<FMT>::T pair_t;
@@ -60,7 +60,11 @@ __device__ __forceinline__ void rcas_strip(const RcasArgs& a, int frame, int x0,
       const pair_t pr = *reinterpret_cast<const pair_t*>(in_col + (long long)y * a.in.pitch);
       __builtin_memcpy(&r.p0, &pr, sizeof(texel_t));
       __builtin_memcpy(&r.p1, reinterpret_cast<const char*>(&pr) + sizeof(texel_t), sizeof(texel_t));
+#ifdef FSR1_RCAS_NO_HALO  // timing experiment only (wrong at strip edges)
+      r.halo = r.p0;
+#else
       r.halo = *reinterpret_cast<const texel_t*>(in_hcol + (long long)y * a.in.pitch);
+#endif
     } else {
       r.p0 = Pixel<FMT>::zero();
       r.p1 = Pixel<FMT>::zero();
@@ -90,7 +94,7 @@ __device__ __forceinline__ void rcas_strip(const RcasArgs& a, int frame, int x0,
   // ahead of the arithmetic.  The row loop is unrolled by kRing, so every ring index is static, and rolled
   // beyond that so the body stays inside the instruction cache.
   // (the colour variants inline two epilogues per row: a shorter unroll keeps them inside the instruction cache)
-  constexpr int kRing = (FMT == FSR1_FORMAT_RGBA32F || COLOR) ? 4 : kRcasRing, kAhead = kRing - 1;  // both divide 8
+  constexpr int kRing = RING, kAhead = kRing - 1;  // divides every strip height the launcher picks (multiples of 8)
   row_t q[kRing];
   rgb_t prev0, prev1, cur0, cur1;
   {
@@ -149,7 +153,11 @@ __device__ __forceinline__ void rcas_strip(const RcasArgs& a, int frame, int x0,
 }
 
 // OPTS = false: the plain pass (no denoise / alpha pass-through / HDR square), flags compiled out.
-template <int FMT, bool EXACT, bool OPTS, bool COLOR = false, int FOUT = FMT>
+// RING: rows in flight per lane.  A deep ring (8: loads 7 rows ahead) hides HBM latency when the launch has waves to
+// spare — batches — but costs 102 VGPRs, 4 waves per SIMD; a single 4K frame is only 4 waves per SIMD to begin with, and
+// there the pass is paced by its own arithmetic (dependent min/max/rcp chains), which a 64-VGPR body with a 2-row ring
+// and twice the resident waves serves better (cold 4K frame: 37.6 -> 30.8 us).  rcas_launch picks by wave count.
+template <int FMT, bool EXACT, bool OPTS, bool COLOR = false, int FOUT = FMT, int RING = ((FMT == FSR1_FORMAT_RGBA32F || COLOR) ? 4 : kRcasRing)>
 __global__ void __launch_bounds__(kRcasThreads) rcas_kernel(const RcasArgs a) {
   const int tiles_per_frame = a.tiles_x * a.tiles_y;
   const int t = xcd_swizzle(blockIdx.x, tiles_per_frame * a.frames);
@@ -160,8 +168,8 @@ __global__ void __launch_bounds__(kRcasThreads) rcas_kernel(const RcasArgs a) {
   const int x0 = tx * kRcasCols + wave * kRcasWaveCols, y0 = ty * a.rows;
   if (x0 >= a.in.width) return;  // whole wave outside (no barriers in this kernel)
   const bool interior = x0 >= 1 && x0 + kRcasWaveCols + 1 <= a.in.width && y0 >= 1 && y0 + a.rows + 1 <= a.in.height;
-  if (interior) rcas_strip<FMT, EXACT, OPTS, true, COLOR, FOUT>(a, frame, x0, y0, lane);
-  else rcas_strip<FMT, EXACT, OPTS, false, COLOR, FOUT>(a, frame, x0, y0, lane);
+  if (interior) rcas_strip<FMT, EXACT, OPTS, true, COLOR, FOUT, RING>(a, frame, x0, y0, lane);
+  else rcas_strip<FMT, EXACT, OPTS, false, COLOR, FOUT, RING>(a, frame, x0, y0, lane);
 }
 
 }  // namespace fsr1
