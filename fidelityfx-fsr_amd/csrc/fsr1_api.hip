@@ -22,6 +22,7 @@ hipError_t easu_color_launch(const EasuArgs& a, int fin, int fout, bool exact, h
 hipError_t rcas_color_launch(const RcasArgs& a, int fin, int fout, bool exact, hipStream_t stream);
 hipError_t fused_color_launch(const FusedArgs& a, int fin, int fout, bool exact, hipStream_t stream);
 hipError_t color_launch(const ColorPassArgs& a, int fin, int fout, bool exact, hipStream_t stream);
+hipError_t color_h_launch(const ColorPassArgs& a, hipStream_t stream);
 void color_geometry(int width, int height, int* tiles_x, int* tiles_y);
 hipError_t rcas_h_launch(const RcasArgs& a, hipStream_t stream);
 }  // namespace fsr1
@@ -317,7 +318,9 @@ int fsr1_color_dispatch(const fsr1_image* in, const fsr1_image* out, const fsr1_
                         void* stream) {
   ColorPassArgs a;
   int rc;
-  if (flags & ~(uint32_t)FSR1_FLAG_MATH_EXACT) return fail(FSR1_ERR_INVALID_ARGUMENT, "color: flags may only hold FSR1_FLAG_MATH_EXACT");
+  if (flags & ~(uint32_t)(FSR1_FLAG_MATH_EXACT | FSR1_FLAG_MATH_PACKED_FP16))
+    return fail(FSR1_ERR_INVALID_ARGUMENT, "color: flags may only hold FSR1_FLAG_MATH_EXACT or FSR1_FLAG_MATH_PACKED_FP16");
+  if ((rc = check_flags(flags))) return rc;
   if ((rc = check_image(in, "color input", &a.in))) return rc;
   if ((rc = check_image(out, "color output", &a.out))) return rc;
   if ((rc = check_color(stages, "color", &a.color))) return rc;
@@ -329,7 +332,14 @@ int fsr1_color_dispatch(const fsr1_image* in, const fsr1_image* out, const fsr1_
     return fail(FSR1_ERR_INVALID_ARGUMENT, "color: input and output overlap without being the same image");
   color_geometry(out->width, out->height, &a.tiles_x, &a.tiles_y);
   a.frames = out->frames;
-  hipError_t e = color_launch(a, in->format, out->format, (flags & FSR1_FLAG_MATH_EXACT) != 0, static_cast<hipStream_t>(stream));
+  hipError_t e;
+  if (flags & FSR1_FLAG_MATH_PACKED_FP16) {
+    if (in->format != FSR1_FORMAT_RGBA16F || out->format != FSR1_FORMAT_RGBA16F)
+      return fail(FSR1_ERR_UNSUPPORTED, "color: packed-fp16 math needs RGBA16F images");
+    e = color_h_launch(a, static_cast<hipStream_t>(stream));
+  } else {
+    e = color_launch(a, in->format, out->format, (flags & FSR1_FLAG_MATH_EXACT) != 0, static_cast<hipStream_t>(stream));
+  }
   if (e != hipSuccess) return hip_fail(e, "color launch");
   return FSR1_OK;
 }

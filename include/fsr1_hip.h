@@ -169,7 +169,9 @@ typedef struct fsr1_color_stages {
 
 /* Stand-alone pass: out[frame] = stages(in[frame]); in and out have the same size and may have different formats
  * (e.g. RGBA16F -> RGBA8_UNORM with FSR1_COLOR_TEPD_C8); in == out (in place) is allowed when the formats match.
- * flags: FSR1_FLAG_MATH_EXACT or 0. */
+ * flags: 0, FSR1_FLAG_MATH_EXACT, or FSR1_FLAG_MATH_PACKED_FP16 — the half-precision entry points FsrSrtmH /
+ * FsrLfgaH / FsrSrtmInvH / FsrTepdC8H | C10H (+ their Hx2 forms; ffx_fsr1.h:1017-1024, :1048-1056, :1124-1198), RGBA16F
+ * in and out, parity class "H" (bit-identical to the reference's CPU-evaluated H path). */
 int fsr1_color_dispatch(const fsr1_image* in, const fsr1_image* out, const fsr1_color_stages* stages, uint32_t flags,
                         void* stream);
 

@@ -67,9 +67,10 @@ class _Oracle:
             fn = g(prefix + n)
             fn.argtypes = [_FP, _I, _I, _FP, _U32P, _I, _I, _I]
             fn.restype = None
-        fn = g(prefix + "color_f")
-        fn.argtypes = [_FP, _I, _I, _FP, _I, _F, _F, ctypes.c_uint32, _FP, _I, _I, _I, _I, _I, _I, _I]
-        fn.restype = None
+        for n in ("color_f", "color_h"):
+            fn = g(prefix + n)
+            fn.argtypes = [_FP, _I, _I, _FP, _I, _F, _F, ctypes.c_uint32, _FP, _I, _I, _I, _I, _I, _I, _I]
+            fn.restype = None
         fn = g(prefix + "tepd_dit_f")
         fn.argtypes = [ctypes.c_uint32] * 3
         fn.restype = _F
@@ -130,7 +131,11 @@ class _Oracle:
 
 
     # ---- colour stages (LFGA / SRTM / TEPD) -------------------------------------------------
-    def color_f(self, img, stages, amount=0.0, bias=0.0, frame=0, noise=None, noise_offset=(0, 0), rows=None):
+    def color_h(self, img, stages, **kw):
+        """The same chain through the half-precision entry points (FsrSrtmH, FsrLfgaH, FsrTepdC8H ...); binary16-representable values."""
+        return self.color_f(img, stages, _entry="color_h", **kw)
+
+    def color_f(self, img, stages, amount=0.0, bias=0.0, frame=0, noise=None, noise_offset=(0, 0), rows=None, _entry="color_f"):
         """Stage chain SRTM -> LFGA -> SRTM_INV -> TEPD on an (H, W, 4) float image; noise is (S, nH, nW, 4) or (nH, nW, 4)."""
         img = np.ascontiguousarray(img, np.float32)
         h, w, _ = img.shape
@@ -145,7 +150,7 @@ class _Oracle:
         else:
             ns = nh = nw = 1
             nptr = ctypes.cast(None, _FP)
-        getattr(self.lib, self._prefix + "color_f")(img.ctypes.data_as(_FP), w, h, out.ctypes.data_as(_FP), int(stages),
+        getattr(self.lib, self._prefix + _entry)(img.ctypes.data_as(_FP), w, h, out.ctypes.data_as(_FP), int(stages),
                                                     float(amount), float(bias), int(frame), nptr, nw, nh, ns,
                                                     int(noise_offset[0]), int(noise_offset[1]), y0, y1)
         return out

@@ -669,3 +669,69 @@ void oracle_color_f(const float* in, int W, int H, float* out, int stages, float
 }
 
 float oracle_tepd_dit_f(uint32_t x, uint32_t y, uint32_t f) { return FsrTepdDitF(x, y, f); }
+
+/* ------------------------------------------------------------------------------------------ */
+/* colour stages, half-precision entry points (ffx_fsr1.h:1017-1024, :1048-1056, :1124-1198)    */
+/* every operation rounded once to binary16, like the other H restatements above               */
+/* ------------------------------------------------------------------------------------------ */
+static inline hf AGtZeroH1(hf m) { return hsat(hmul(m, INFINITY)); }                      /* ffx_a.h:1524 */
+static inline hf AMax3H1(hf a, hf b, hf c) { return hmax(a, hmax(b, c)); }
+
+/* :1049 FsrSrtmH / :1050 FsrSrtmInvH (ARcpH1 = correctly rounded 1/x) */
+static inline void FsrSrtmH(hf c[3]) {
+  hf r = hdiv(1.0f, hadd(AMax3H1(c[0], c[1], c[2]), 1.0f));
+  c[0] = hmul(c[0], r); c[1] = hmul(c[1], r); c[2] = hmul(c[2], r);
+}
+static inline void FsrSrtmInvH(hf c[3]) {
+  hf r = hdiv(1.0f, hmax(hround(1.0 / 32768.0), hsub(1.0f, AMax3H1(c[0], c[1], c[2]))));
+  c[0] = hmul(c[0], r); c[1] = hmul(c[1], r); c[2] = hmul(c[2], r);
+}
+/* :1019 FsrLfgaH */
+static inline void FsrLfgaH(hf c[3], const hf t[3], hf a) {
+  for (int i = 0; i < 3; ++i) c[i] = hadd(c[i], hmul(hmul(t[i], a), hmin(hsub(1.0f, c[i]), c[i])));
+}
+/* :1125-1131 FsrTepdDitH: binary32 arithmetic, the result narrowed once */
+static inline hf FsrTepdDitH(uint32_t px, uint32_t py, uint32_t f) { return hround((double)FsrTepdDitF(px, py, f)); }
+/* :1134-1150 FsrTepdC8H / FsrTepdC10H */
+static inline void FsrTepdCH(hf c[3], hf dit, double steps) {
+  const hf k = hround(steps), rk = hround(1.0 / steps);
+  for (int i = 0; i < 3; ++i) {
+    hf n = hround(sqrt((double)c[i]));
+    n = hmul(floorf(hmul(n, k)), rk);
+    hf a = hmul(n, n);
+    hf b = hadd(n, rk);
+    b = hmul(b, b);
+    hf r = hmul(hsub(c[i], b), APrxMedRcpH1(hsub(a, b)));
+    c[i] = hsat(hadd(n, hmul(AGtZeroH1(hsub(dit, r)), rk)));
+  }
+}
+
+void oracle_color_h(const float* in, int W, int H, float* out, int stages, float amount, float bias, uint32_t frame,
+                    const float* noise, int nW, int nH, int nS, int nox, int noy, int y0, int y1) {
+  (void)H;
+#pragma omp parallel for schedule(dynamic, 4)
+  for (int y = y0; y < y1; ++y)
+    for (int x = 0; x < W; ++x) {
+      const float* q = in + ((size_t)y * W + x) * 4;
+      hf c[3] = {hround(q[0]), hround(q[1]), hround(q[2])};
+      float n[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+      if (noise) {
+        const int ny = (int)((((long long)y + noy) % nH + nH) % nH), nx = (int)((((long long)x + nox) % nW + nW) % nW);
+        const float* t = noise + (((size_t)(frame % (uint32_t)nS) * nH + ny) * nW + nx) * 4;
+        n[0] = t[0]; n[1] = t[1]; n[2] = t[2]; n[3] = t[3];
+      }
+      const hf hb = hround(bias), ha = hround(amount);
+      if (stages & ORACLE_COLOR_SRTM) FsrSrtmH(c);
+      if (stages & ORACLE_COLOR_LFGA) {
+        const hf t[3] = {hadd(hround(n[0]), hb), hadd(hround(n[1]), hb), hadd(hround(n[2]), hb)};
+        FsrLfgaH(c, t, ha);
+      }
+      if (stages & ORACLE_COLOR_SRTM_INV) FsrSrtmInvH(c);
+      if (stages & (ORACLE_COLOR_TEPD_C8 | ORACLE_COLOR_TEPD_C10)) {
+        const hf dit = (stages & ORACLE_COLOR_DITHER_FROM_NOISE) ? hsat(hround(n[3])) : FsrTepdDitH((uint32_t)x, (uint32_t)y, frame);
+        FsrTepdCH(c, dit, (stages & ORACLE_COLOR_TEPD_C8) ? 255.0 : 1023.0);
+      }
+      float* o = out + ((size_t)y * W + x) * 4;
+      o[0] = c[0]; o[1] = c[1]; o[2] = c[2]; o[3] = q[3];
+    }
+}

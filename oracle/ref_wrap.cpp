@@ -214,6 +214,37 @@ void ref_color_f(const float* in, int W, int H, float* out, int stages, float am
   }
 }
 
+// The same chain through the reference's half-precision entry points: FsrSrtmH (:1049) -> FsrLfgaH (:1019) ->
+// FsrSrtmInvH (:1050) -> FsrTepdC8H | FsrTepdC10H (:1134, :1143) with FsrTepdDitH (:1125).  (The Hx2 forms, :1022,
+// :1052-1055, :1153-1198, run the same operations per lane.)  Values are binary16-representable floats.
+void ref_color_h(const float* in, int W, int H, float* out, int stages, float amount, float bias, uint32_t frame,
+                 const float* noise, int nW, int nH, int nS, int nox, int noy, int y0, int y1) {
+#pragma omp parallel for schedule(dynamic, 4)
+  for (int y = y0; y < y1; ++y) {
+    for (int x = 0; x < W; ++x) {
+      const float* q = in + ((size_t)y * W + x) * 4;
+      f16vec3 c = f16vec3(float16_t(q[0]), float16_t(q[1]), float16_t(q[2]));
+      float n[4] = {0.f, 0.f, 0.f, 0.f};
+      if (noise) {
+        const int ny = (int)((((long long)y + noy) % nH + nH) % nH), nx = (int)((((long long)x + nox) % nW + nW) % nW);
+        const float* t = noise + (((size_t)(frame % (uint32_t)nS) * nH + ny) * nW + nx) * 4;
+        n[0] = t[0]; n[1] = t[1]; n[2] = t[2]; n[3] = t[3];
+      }
+      const float16_t hb(bias), ha(amount);
+      if (stages & REF_COLOR_SRTM) plain::FsrSrtmH(c);
+      if (stages & REF_COLOR_LFGA) plain::FsrLfgaH(c, f16vec3(float16_t(n[0]) + hb, float16_t(n[1]) + hb, float16_t(n[2]) + hb), ha);
+      if (stages & REF_COLOR_SRTM_INV) plain::FsrSrtmInvH(c);
+      if (stages & (REF_COLOR_TEPD_C8 | REF_COLOR_TEPD_C10)) {
+        const float16_t dit = (stages & REF_COLOR_DITHER_FROM_NOISE) ? plain::ASatH1(float16_t(n[3]))
+                                                                      : plain::FsrTepdDitH(uvec2((uint)x, (uint)y), frame);
+        if (stages & REF_COLOR_TEPD_C8) plain::FsrTepdC8H(c, dit); else plain::FsrTepdC10H(c, dit);
+      }
+      float* o = out + ((size_t)y * W + x) * 4;
+      o[0] = c.x.v; o[1] = c.y.v; o[2] = c.z.v; o[3] = q[3];
+    }
+  }
+}
+
 // FsrTepdDitF alone (:1082-1091), for the known-answer tests.
 float ref_tepd_dit_f(uint32_t x, uint32_t y, uint32_t f) { return plain::FsrTepdDitF(uvec2(x, y), f); }
 

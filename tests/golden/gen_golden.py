@@ -72,6 +72,8 @@ def write_color(R):
     out = {"ldr": ldr.astype(np.float16), "hdr": hdr.astype(np.float16), "noise": noise.astype(np.float16)}
     for st, key in COLOR_CASES:
         out["out_%d_%s" % (st, key)] = R.color_f({"ldr": ldr, "hdr": hdr}[key], st, noise=noise, **COLOR_PARAMS)
+        # the half-precision entry points (FsrSrtmH, FsrLfgaH, FsrTepdC8H ...) on the same inputs
+        out["outh_%d_%s" % (st, key)] = R.color_h({"ldr": ldr, "hdr": hdr}[key], st, noise=noise, **COLOR_PARAMS).astype(np.float16)
     out["dit"] = np.array([[R.FsrTepdDitF(x, y, f) for x in (0, 1, 17, 3839, 7679)] for y, f in ((0, 0), (5, 1), (2159, 7), (4319, 1000))],
                           np.float32)
     np.savez_compressed(os.path.join(HERE, "color_stages.npz"), **out)

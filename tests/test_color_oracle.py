@@ -32,6 +32,33 @@ def test_port_matches_golden_color(port):
     assert same_bits(dit, g["dit"])
 
 
+def test_port_matches_golden_color_h(port):
+    """Half-precision entry points (FsrSrtmH, FsrLfgaH, FsrSrtmInvH, FsrTepdC8H / C10H): restatement vs the committed vectors."""
+    g = load_golden("color_stages")
+    noise = g["noise"].astype(np.float32)
+    n = 0
+    for k in sorted(g):
+        if k.startswith("outh_"):
+            _, st, key = k.split("_")
+            got = port.color_h(g[key].astype(np.float32), int(st), noise=noise, **PARAMS)
+            assert same_bits(got, g[k].astype(np.float32)), (st, key)
+            n += 1
+    assert n == 12
+
+
+@pytest.mark.parametrize("stages", [1, 2, 4, 8, 16, 8 | 32, 2 | 8, 1 | 2 | 4, 2 | 16 | 32])
+def test_port_matches_reference_build_color_h(port, ref, stages):
+    rng = np.random.default_rng(50 + stages)
+    img = rng.random((29, 43, 4)).astype(np.float32)
+    if stages & 1:
+        img[..., :3] = img[..., :3] ** 4 * 30000.0
+    img = img.astype(np.float16).astype(np.float32)
+    noise = (rng.random((2, 5, 7, 4)).astype(np.float32) - np.array([0.5, 0.5, 0.5, 0.0], np.float32)).astype(np.float16).astype(np.float32)
+    for frame in (0, 3, 77777):
+        kw = dict(amount=0.4, bias=0.1, frame=frame, noise=noise, noise_offset=(-11, 13))
+        assert same_bits(ref.color_h(img, stages, **kw), port.color_h(img, stages, **kw)), frame
+
+
 @pytest.mark.parametrize("stages", [1, 2, 4, 8, 16, 8 | 32, 2 | 8, 2 | 4, 1 | 2 | 4, 1 | 2 | 16, 2 | 16 | 32])
 def test_port_matches_reference_build_color(port, ref, stages):
     rng = np.random.default_rng(stages)

@@ -246,3 +246,38 @@ def test_upscale_with_colour_stages(fsr, port, fused):
     want = port.color_f(port.easu_f(pre, ow, oh, con), st & ~1, noise=noise.astype(np.float32), **p)
     assert_exact16(host(dst), want, "Upscale (EASU only) + stages")
     filt.OnDestroy()
+
+
+@pytest.mark.parametrize("stages", [1, 2, 4, 8, 16, 8 | 32, 2 | 8, 2 | 4, 1 | 2 | 4, 2 | 16 | 32])
+def test_color_pass_packed_fp16(fsr, port, stages):
+    """FSR1_FLAG_MATH_PACKED_FP16: FsrSrtmH / FsrLfgaH / FsrSrtmInvH / FsrTepdC8H | C10H (Hx2 forms, two pixels per AH2) —
+    parity class H: every binary16 output bit equals the CPU-evaluated half-precision path; ragged size, fp16 noise."""
+    rng = np.random.default_rng(200 + stages)
+    h, w = 45, 131
+    img = rng.random((h, w, 4)).astype(np.float32)
+    if stages & 1:
+        img[..., :3] = img[..., :3] ** 4 * 20000.0
+    img[0, :5, :3] = np.array([0.0, 1.0, 0.5, 6e-8, 0.25], np.float32)[:, None]
+    img = img.astype(np.float16)
+    noise = (rng.random((3, 16, 24, 4)).astype(np.float32) - np.array([0.5, 0.5, 0.5, 0.0], np.float32)).astype(np.float16)
+    p = dict(amount=0.6, bias=0.05, frame=7, noise_offset=(-9, 1000))
+    want = port.color_h(img.astype(np.float32), stages, noise=noise.astype(np.float32), **p)
+    dst = torch.zeros(h, w, 4, dtype=torch.float16, device="cuda")
+    fsr.color(dev(img), dst, stages_of(fsr, stages, dev(noise), p), flags=fsr.FLAG_MATH_PACKED_FP16)
+    assert_exact16(host(dst), want, "H stages %d" % stages)
+
+
+def test_color_pass_packed_fp16_golden(fsr):
+    g = load_golden("color_stages")
+    noise = dev(g["noise"])
+    n = 0
+    for k in sorted(g):
+        if not k.startswith("outh_"):
+            continue
+        _, st, key = k.split("_")
+        src = dev(g[key])
+        dst = torch.zeros_like(src)
+        fsr.color(src, dst, stages_of(fsr, int(st), noise), flags=fsr.FLAG_MATH_PACKED_FP16)
+        assert_exact16(host(dst), g[k].astype(np.float32), "H golden stages %s on %s" % (st, key))
+        n += 1
+    assert n == 12
