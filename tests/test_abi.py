@@ -109,3 +109,20 @@ def test_header_is_plain_c(tmp_path):
     inc = os.path.join(ROOT, "include")
     subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I", inc, "-fsyntax-only", str(src)])
     subprocess.check_call(["g++", "-std=c++11", "-Wall", "-Werror", "-I", inc, "-fsyntax-only", "-x", "c++", str(src)])
+
+
+def test_upscale_parameter_validation(fsr):
+    """fsr1_upscale rejects an unknown pipeline selector and stray flag bits before anything is launched."""
+    lib = fsr.load()
+    a = fsr.fsr1_image(0x1000, 16, 16, 0, 1, 0, 0)
+    b = fsr.fsr1_image(0x100000, 32, 32, 0, 1, 0, 0)
+    m = fsr.fsr1_image(0x200000, 32, 32, 0, 1, 0, 0)
+    P = fsr._lib.fsr1_params
+    bad = P(16.0, 16.0, 1, 0.25, 0, 3, 0)            # fused must be 0, 1 or 2
+    assert lib.fsr1_upscale(ctypes.byref(a), ctypes.byref(m), ctypes.byref(b), ctypes.byref(bad), None) == -1
+    assert b"fused" in lib.fsr1_last_error()
+    bad = P(16.0, 16.0, 1, 0.25, 0, 0, 1)            # HDR_SQUARE is derived from `hdr`, not passed in flags
+    assert lib.fsr1_upscale(ctypes.byref(a), ctypes.byref(m), ctypes.byref(b), ctypes.byref(bad), None) == -1
+    ok = P(16.0, 16.0, 1, 0.25, 0, 0, 1 << 8)        # NO_FAST_PATHS is a legal arithmetic-selection bit; no intermediary given
+    assert lib.fsr1_upscale(ctypes.byref(a), None, ctypes.byref(b), ctypes.byref(ok), None) == -1
+    assert b"intermediary" in lib.fsr1_last_error()
