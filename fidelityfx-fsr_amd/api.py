@@ -95,6 +95,7 @@ def image_of(t):
         sn, sh, sw = t.stride()
         if sw != 1:
             raise Fsr1Error("pixels must be dense along x")
+        _check_strides(n, h, w, sn, sh, 1)
         return fsr1_image(t.data_ptr(), w, h, FORMAT_R10G10B10A2_UNORM, n, sh * 4, sn * 4 if n > 1 else 0)
     if t.dim() == 3:
         t = t.unsqueeze(0)
@@ -112,7 +113,17 @@ def image_of(t):
     sn, sh, sw, sc = t.stride()
     if sc != 1 or sw != 4:
         raise Fsr1Error("pixels must be RGBA-interleaved and dense along x")
+    _check_strides(n, h, w, sn, sh, 4)
     return fsr1_image(t.data_ptr(), w, h, fmt, n, sh * es, sn * es if n > 1 else 0)
+
+
+def _check_strides(n, h, w, sn, sh, elems_per_pixel):
+    """The C ABI reads a pitch / frame stride of 0 as "tightly packed", so an expanded / broadcast view (stride 0) or an
+    overlapping one must not reach it: rows and frames have to be distinct memory."""
+    if h > 1 and sh < w * elems_per_pixel:
+        raise Fsr1Error("row stride %d elements is smaller than a row of %d pixels (expanded or overlapping view?)" % (sh, w))
+    if n > 1 and sn < sh * h:
+        raise Fsr1Error("frame stride %d elements is smaller than one frame (expanded or overlapping view?)" % sn)
 
 
 def _stream_ptr(stream):

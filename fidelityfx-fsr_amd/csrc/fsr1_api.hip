@@ -112,6 +112,13 @@ static int footprint_extent(int out_size, int tile, int apron, float scale, floa
   return best;
 }
 
+// Launch grids are one-dimensional: tiles_x * tiles_y * frames workgroups, formed in int on the device.
+static int check_grid(const char* who, int tiles_x, int tiles_y, int frames) {
+  const long long total = (long long)tiles_x * (long long)tiles_y * (long long)frames;
+  if (total <= 0 || total > 0x7fffffffLL) return fail(FSR1_ERR_UNSUPPORTED, "%s: %lld workgroups exceed the launch grid limit; split the batch", who, total);
+  return FSR1_OK;
+}
+
 static const uint32_t kKnownFlags = FSR1_FLAG_HDR_SQUARE | FSR1_FLAG_RCAS_DENOISE | FSR1_FLAG_RCAS_PASSTHROUGH_ALPHA |
                                     FSR1_FLAG_MATH_EXACT | FSR1_FLAG_MATH_PACKED_FP16 | FSR1_FLAG_NO_FAST_PATHS;
 
@@ -205,6 +212,8 @@ int fsr1_easu_dispatch_ex(const fsr1_image* in, const fsr1_image* out, const uin
   if (easu_lds_bytes(in->format, a.fp_w, a.fp_h) > 160 * 1024)
     return fail(FSR1_ERR_UNSUPPORTED, "easu: input/output ratio (%g, %g) needs a %dx%d texel footprint per tile, beyond the LDS budget "
                                       "(EASU is an upscaler; ratios up to ~3x minification are supported)", sx, sy, a.fp_w, a.fp_h);
+  if ((long long)(a.fp_h + 1) * a.in.pitch >= (1ll << 31))  // staging addresses texels as row base + 32-bit offset
+    return fail(FSR1_ERR_UNSUPPORTED, "easu: input row pitch %lld too large for a %d-row footprint", a.in.pitch, a.fp_h);
   a.tiles_x = (out->width + kTileW - 1) / kTileW;
   a.tiles_y = (out->height + kTileH - 1) / kTileH;
   a.frames = out->frames;
@@ -220,6 +229,7 @@ int fsr1_easu_dispatch_ex(const fsr1_image* in, const fsr1_image* out, const uin
     a.fp_w = kTileW / 2 + 3;
     a.fp_h = kTileH / 2 + 3;
   }
+  if ((rc = check_grid("easu", a.tiles_x, a.tiles_y, a.frames))) return rc;
   hipError_t e;
   if (flags & FSR1_FLAG_MATH_PACKED_FP16) {
     if (in->format != FSR1_FORMAT_RGBA16F) return fail(FSR1_ERR_UNSUPPORTED, "easu: packed-fp16 math needs RGBA16F images");
@@ -256,6 +266,7 @@ int fsr1_rcas_dispatch_ex(const fsr1_image* in, const fsr1_image* out, const uin
   memcpy(a.con, con, sizeof a.con);
   rcas_geometry(out->width, out->height, out->frames, &a.tiles_x, &a.tiles_y, &a.rows);
   a.frames = out->frames;
+  if ((rc = check_grid("rcas", a.tiles_x, a.tiles_y, a.frames))) return rc;
   a.flags = flags;
   hipError_t e;
   if (flags & FSR1_FLAG_MATH_PACKED_FP16) {
@@ -302,9 +313,12 @@ int fsr1_easu_rcas_fused_dispatch_ex(const fsr1_image* in, const fsr1_image* out
   if (a.fp_w < 0 || a.fp_h < 0) return fail(FSR1_ERR_INVALID_ARGUMENT, "fused: scale constants con0.xy = (%g, %g) are not usable", sx, sy);
   if (fused_lds_bytes(in->format, a.fp_w, a.fp_h) > 160 * 1024)
     return fail(FSR1_ERR_UNSUPPORTED, "fused: input/output ratio (%g, %g) needs more LDS than a CU has", sx, sy);
+  if ((long long)(a.fp_h + 1) * a.in.pitch >= (1ll << 31))
+    return fail(FSR1_ERR_UNSUPPORTED, "fused: input row pitch %lld too large for a %d-row footprint", a.in.pitch, a.fp_h);
   a.tiles_x = (out->width + kTileW - 1) / kTileW;
   a.tiles_y = (out->height + kFusedTileH - 1) / kFusedTileH;
   a.frames = out->frames;
+  if ((rc = check_grid("fused", a.tiles_x, a.tiles_y, a.frames))) return rc;
   a.flags = flags;
   const bool exact = (flags & FSR1_FLAG_MATH_EXACT) != 0;
   hipError_t e = a.color.stages ? fused_color_launch(a, in->format, out->format, exact, static_cast<hipStream_t>(stream))
@@ -332,6 +346,7 @@ int fsr1_color_dispatch(const fsr1_image* in, const fsr1_image* out, const fsr1_
     return fail(FSR1_ERR_INVALID_ARGUMENT, "color: input and output overlap without being the same image");
   color_geometry(out->width, out->height, &a.tiles_x, &a.tiles_y);
   a.frames = out->frames;
+  if ((rc = check_grid("color", a.tiles_x, a.tiles_y, a.frames))) return rc;
   hipError_t e;
   if (flags & FSR1_FLAG_MATH_PACKED_FP16) {
     if (in->format != FSR1_FORMAT_RGBA16F || out->format != FSR1_FORMAT_RGBA16F)
@@ -353,6 +368,9 @@ int fsr1_upscale(const fsr1_image* in, const fsr1_image* intermediary, const fsr
 int fsr1_upscale_ex(const fsr1_image* in, const fsr1_image* intermediary, const fsr1_image* out, const fsr1_params* p,
                     const fsr1_color_stages* stages, void* stream) {
   if (!in || !out || !p) return fail(FSR1_ERR_INVALID_ARGUMENT, "upscale: null argument");
+  if (!(p->render_width >= 1.0f) || !(p->render_height >= 1.0f) || p->render_width > (float)in->width || p->render_height > (float)in->height)
+    return fail(FSR1_ERR_INVALID_ARGUMENT, "upscale: render size %gx%g must lie within the input image %dx%d", (double)p->render_width,
+                (double)p->render_height, in->width, in->height);
   uint32_t easu_con[16], rcas_con[4];
   // :106 — viewport == input resource size == (renderWidth, renderHeight); output = display size
   FsrEasuCon(easu_con, easu_con + 4, easu_con + 8, easu_con + 12, p->render_width, p->render_height, p->render_width,
@@ -373,6 +391,10 @@ int fsr1_upscale_ex(const fsr1_image* in, const fsr1_image* intermediary, const 
     memcpy(&sx, &easu_con[0], 4);
     memcpy(&sy, &easu_con[1], 4);
     fused = !intermediary || (sx <= 0.55f && sy <= 0.55f);
+    if (math & FSR1_FLAG_MATH_PACKED_FP16) {  // FsrEasuH / FsrRcasH exist as two dispatches only
+      if (!intermediary) return fail(FSR1_ERR_INVALID_ARGUMENT, "upscale: packed-fp16 math runs as two dispatches and needs an intermediary image");
+      fused = false;
+    }
   } else if (p->fused != 0 && p->fused != 1) {
     return fail(FSR1_ERR_INVALID_ARGUMENT, "upscale: params.fused must be 0, 1 or 2 (auto)");
   }

@@ -8,6 +8,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include "fsr1_hip.h"
 
 namespace fsr1 {
@@ -118,6 +120,34 @@ __device__ __forceinline__ int xcd_swizzle(int b, int n) {
   const int q = n / kXcds, r = n % kXcds;
   const int xcd = b % kXcds, idx = b / kXcds;
   return xcd * q + (xcd < r ? xcd : r) + idx;
+}
+
+// Kernels that may need more than the default 48 KiB of dynamic LDS ask for it through hipFuncSetAttribute — once per
+// kernel, device and size: the attribute sticks, and re-issuing the call on every launch costs host time on the
+// launch path (round 1 did).  The cache is keyed by (device, function) and only ever grows.
+inline hipError_t ensure_dynamic_lds(const void* fn, size_t lds) {
+  if (lds <= 48 * 1024) return hipSuccess;
+  struct Slot { std::atomic<const void*> fn{nullptr}; std::atomic<size_t> bytes{0}; };
+  constexpr int kDevices = 16, kSlots = 64;
+  static Slot cache[kDevices][kSlots];
+  int dev = 0;
+  if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
+  Slot* row = cache[dev >= 0 && dev < kDevices ? dev : 0];
+  Slot* slot = nullptr;
+  if (dev >= 0 && dev < kDevices) {
+    for (int i = 0; i < kSlots && !slot; ++i) {
+      const void* cur = row[i].fn.load(std::memory_order_acquire);
+      if (cur == fn) slot = &row[i];
+      else if (!cur) {
+        const void* expected = nullptr;
+        if (row[i].fn.compare_exchange_strong(expected, fn, std::memory_order_acq_rel) || expected == fn) slot = &row[i];
+      }
+    }
+  }
+  if (slot && slot->bytes.load(std::memory_order_acquire) >= lds) return hipSuccess;
+  if (hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); e != hipSuccess) return e;
+  if (slot) slot->bytes.store(lds, std::memory_order_release);
+  return hipSuccess;
 }
 
 // Optimisation barrier for a value that is about to be narrowed.  LLVM folds fptrunc(fmul) / fptrunc(fma)

@@ -36,9 +36,17 @@ size_t easu_lds_bytes(int fmt, int fp_w, int fp_h) {
 
 // s2: launch the exact-2x variant (the caller has checked con0 and laid the grid out for the shifted tiles).
 hipError_t easu_launch(const EasuArgs& a, int fmt, bool exact, bool s2, hipStream_t stream) {
-#define FSR1_LAUNCH_E(F)                                                                                                \
-  return s2 ? (exact ? easu_launch_one<F, true, false, F, true>(a, stream) : easu_launch_one<F, false, false, F, true>(a, stream)) \
-            : (exact ? easu_launch_one<F, true, false, F, false>(a, stream) : easu_launch_one<F, false, false, F, false>(a, stream))
+  const bool hdr = (a.flags & FSR1_FLAG_HDR_SQUARE) != 0;
+#define FSR1_LAUNCH_H(F, E, S) return hdr ? easu_launch_one<F, E, false, F, S, true>(a, stream) : easu_launch_one<F, E, false, F, S, false>(a, stream)
+#define FSR1_LAUNCH_E(F)                              \
+  do {                                                \
+    if (s2) {                                         \
+      if (exact) FSR1_LAUNCH_H(F, true, true);        \
+      FSR1_LAUNCH_H(F, false, true);                  \
+    }                                                 \
+    if (exact) FSR1_LAUNCH_H(F, true, false);         \
+    FSR1_LAUNCH_H(F, false, false);                   \
+  } while (0)
   switch (fmt) {
     case FSR1_FORMAT_RGBA16F: FSR1_LAUNCH_E(FSR1_FORMAT_RGBA16F);
     case FSR1_FORMAT_RGBA32F: FSR1_LAUNCH_E(FSR1_FORMAT_RGBA32F);
@@ -47,6 +55,7 @@ hipError_t easu_launch(const EasuArgs& a, int fmt, bool exact, bool s2, hipStrea
     default: return hipErrorInvalidValue;
   }
 #undef FSR1_LAUNCH_E
+#undef FSR1_LAUNCH_H
 }
 
 }  // namespace fsr1

@@ -19,41 +19,33 @@ size_t easu_lds_bytes(int fmt, int fp_w, int fp_h);
 // arithmetic are done once per four pixels and (ppx, ppy) are compile-time constants, which folds the bilinear weights
 // and the tap offsets of easu_pixel (-12 % VALU instructions, same four-pixels-per-lane balance).  The arithmetic per
 // pixel is the same function on the same values: bit-identical to S2 = false (tests/test_gpu_parity.py).
-template <int FMT, bool EXACT, bool COLOR = false, int FOUT = FMT, bool S2 = false>
+template <int FMT, bool EXACT, bool COLOR = false, int FOUT = FMT, bool S2 = false, bool HDR = false>
 __global__ void __launch_bounds__(kThreads) easu_kernel(const EasuArgs a) {
   typedef typename Pixel<FOUT>::T texel_t;
   constexpr bool kS2 = S2 && kTileH % 16 == 0;  // (other tile heights are tuning builds: the host never selects S2 for them)
+  constexpr int kS2W = kTileW / 2 + 3, kS2H = kTileH / 2 + 3;  // footprint of every exact-2x tile
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  EasuLds l = easu_lds_carve(smem, a.fp_w * a.fp_h);
+  EasuLds l = easu_lds_carve(smem, kS2 ? kS2W * kS2H : a.fp_w * a.fp_h);
 
   const int tiles_per_frame = a.tiles_x * a.tiles_y;
   const int t = xcd_swizzle(blockIdx.x, tiles_per_frame * a.frames);
   const int frame = t / tiles_per_frame;
   const int tf = t - frame * tiles_per_frame;
   const int ty = tf / a.tiles_x, tx = tf - ty * a.tiles_x;
-  const int ox0 = tx * kTileW - (kS2 ? 1 : 0), oy0 = ty * kTileH - (kS2 ? 1 : 0);
-
-  const float c0x = as_f32(a.con[0]), c0y = as_f32(a.con[1]), c0z = as_f32(a.con[2]), c0w = as_f32(a.con[3]);
-
-  // Footprint of this tile: fp(first pixel)-1 .. fp(last pixel)+2 per axis (ffx_fsr1.h:324-342).
-  // Same arithmetic as the per-pixel position below, and x -> x*c+b is monotone under rounding.
-  const int oxf = max(ox0, 0), oyf = max(oy0, 0);  // first pixel of the tile inside the image (S2 tiles start at -1)
-  const int oxl = min(ox0 + kTileW, a.out.width) - 1, oyl = min(oy0 + kTileH, a.out.height) - 1;
-  const int fx0 = (int)floorf((float)oxf * c0x + c0z) - 1;
-  const int fy0 = (int)floorf((float)oyf * c0y + c0w) - 1;
-  const int fw = min((int)floorf((float)oxl * c0x + c0z) + 2 - fx0 + 1, a.fp_w);
-  const int fh = min((int)floorf((float)oyl * c0y + c0w) + 2 - fy0 + 1, a.fp_h);
-  l.fw = fw;
-
   const int tid = threadIdx.x;
-  easu_stage_footprint<FMT, COLOR, EXACT>(l, a.in, a.in.base + (long long)frame * a.in.frame_stride, fx0, fy0, fw, fh, tid, &a.color);
-
-  // ---- phase 3: output pixels; a lane owns a column, a wave 4 rows (S2: a lane owns a 2x2 quad, a wave 2 quad rows) ----
   const int lane = tid & 63, wave = tid >> 6;
+  const char* const in_frame = a.in.base + (long long)frame * a.in.frame_stride;
+
   if constexpr (kS2) {
+    // ---- exact 2x: tile (tx, ty) = output pixels [64 tx - 1, 64 tx + 62] x [16 ty - 1, 16 ty + 14] = 32 x 8 quads; quad
+    //      (qx, qy) shares the texel f = (32 tx - 1 + qx, 8 ty - 1 + qy), so the footprint starts two texels before ----
     static_assert(!COLOR && kTileW == 64, "the exact-2x variant is built for the plain 64-wide tiles");
+    const int ox0 = tx * kTileW - 1, oy0 = ty * kTileH - 1;
+    const int fx0 = tx * (kTileW / 2) - 2, fy0 = ty * (kTileH / 2) - 2;
+    l.fw = kS2W;
+    easu_stage_footprint<FMT, false, EXACT, kS2W, kS2H>(l, a.in, in_frame, fx0, fy0, kS2W, kS2H, tid);
     const int W = a.out.width, H = a.out.height;
-    const bool hdr = (a.flags & FSR1_FLAG_HDR_SQUARE) != 0;
+    constexpr bool hdr = HDR;
     struct __attribute__((aligned(sizeof(texel_t)))) pair_t { texel_t p[2]; };
 #pragma unroll 1
     for (int k = 0; k < kTileH / 16; ++k) {
@@ -61,39 +53,55 @@ __global__ void __launch_bounds__(kThreads) easu_kernel(const EasuArgs a) {
       const int oxa = ox0 + 2 * qx, oya = oy0 + 2 * qy;  // odd (ox0, oy0 are): the quad is {oxa, oxa+1} x {oya, oya+1}
       const bool xin0 = oxa >= 0 && oxa < W, xin1 = oxa + 1 < W, yin0 = oya >= 0 && oya < H, yin1 = oya + 1 < H;
       if (!((xin0 || xin1) && (yin0 || yin1))) continue;
-      const int f_idx = (((oya - 1) >> 1) - fy0) * fw + (((oxa - 1) >> 1) - fx0);  // fp = (o - 1) / 2 for odd o, also for o = -1
+      const int f_idx = (qy + 1) * kS2W + (qx + 1);
       char* const o0 = a.out.base + (long long)frame * a.out.frame_stride + (long long)oya * a.out.pitch + (long long)oxa * (long long)sizeof(texel_t);
+      const EasuBounds m = easu_bounds(l, f_idx);  // one 2x2 block for the whole quad
       if (xin0 && xin1 && yin0 && yin1) {
-        // the whole quad lies inside the image (every lane of every tile but those on the image's border): no
-        // predicates, so the 16 LDS loads of the window are shared by the four pixels
+        // the whole quad lies inside the image (every lane of every tile but those on the image's border): no predicates
         pair_t r0, r1;
-        r0.p[0] = easu_resolve<FMT, EXACT>(l, f_idx, easu_pixel<EXACT>(l, f_idx, 0.25f, 0.25f), hdr);
-        r0.p[1] = easu_resolve<FMT, EXACT>(l, f_idx, easu_pixel<EXACT>(l, f_idx, 0.75f, 0.25f), hdr);
-        r1.p[0] = easu_resolve<FMT, EXACT>(l, f_idx, easu_pixel<EXACT>(l, f_idx, 0.25f, 0.75f), hdr);
-        r1.p[1] = easu_resolve<FMT, EXACT>(l, f_idx, easu_pixel<EXACT>(l, f_idx, 0.75f, 0.75f), hdr);
+        r0.p[0] = easu_resolve<FMT, EXACT>(m, easu_pixel<EXACT>(l, f_idx, 0.25f, 0.25f), hdr);
+        r0.p[1] = easu_resolve<FMT, EXACT>(m, easu_pixel<EXACT>(l, f_idx, 0.75f, 0.25f), hdr);
+        r1.p[0] = easu_resolve<FMT, EXACT>(m, easu_pixel<EXACT>(l, f_idx, 0.25f, 0.75f), hdr);
+        r1.p[1] = easu_resolve<FMT, EXACT>(m, easu_pixel<EXACT>(l, f_idx, 0.75f, 0.75f), hdr);
         *reinterpret_cast<pair_t*>(o0) = r0;
         *reinterpret_cast<pair_t*>(o0 + a.out.pitch) = r1;
         continue;
       }
       auto row = [&](char* o, bool yin, float ppy) {
         if (!yin) return;
-        if (xin0) *reinterpret_cast<texel_t*>(o) = easu_resolve<FMT, EXACT>(l, f_idx, easu_pixel<EXACT>(l, f_idx, 0.25f, ppy), hdr);
-        if (xin1) *reinterpret_cast<texel_t*>(o + sizeof(texel_t)) = easu_resolve<FMT, EXACT>(l, f_idx, easu_pixel<EXACT>(l, f_idx, 0.75f, ppy), hdr);
+        if (xin0) *reinterpret_cast<texel_t*>(o) = easu_resolve<FMT, EXACT>(m, easu_pixel<EXACT>(l, f_idx, 0.25f, ppy), hdr);
+        if (xin1) *reinterpret_cast<texel_t*>(o + sizeof(texel_t)) = easu_resolve<FMT, EXACT>(m, easu_pixel<EXACT>(l, f_idx, 0.75f, ppy), hdr);
       };
       row(o0, yin0, 0.25f);
       row(o0 + a.out.pitch, yin1, 0.75f);
     }
     return;
   }
+
+  const int ox0 = tx * kTileW, oy0 = ty * kTileH;
+  const float c0x = as_f32(a.con[0]), c0y = as_f32(a.con[1]), c0z = as_f32(a.con[2]), c0w = as_f32(a.con[3]);
+  // Footprint of this tile: fp(first pixel)-1 .. fp(last pixel)+2 per axis (ffx_fsr1.h:324-342).
+  // Same arithmetic as the per-pixel position below, and x -> x*c+b is monotone under rounding.
+  const int oxl = min(ox0 + kTileW, a.out.width) - 1, oyl = min(oy0 + kTileH, a.out.height) - 1;
+  const int fx0 = (int)floorf((float)ox0 * c0x + c0z) - 1;
+  const int fy0 = (int)floorf((float)oy0 * c0y + c0w) - 1;
+  const int fw = min((int)floorf((float)oxl * c0x + c0z) + 2 - fx0 + 1, a.fp_w);
+  const int fh = min((int)floorf((float)oyl * c0y + c0w) + 2 - fy0 + 1, a.fp_h);
+  l.fw = fw;
+  easu_stage_footprint<FMT, COLOR, EXACT>(l, a.in, in_frame, fx0, fy0, fw, fh, tid, &a.color);
+
+  // ---- phase 3: output pixels; a lane owns a column, a wave kTileH / 4 rows ----
   const int ox = ox0 + lane;
   if (ox >= a.out.width) return;
   char* const out_col = a.out.base + (long long)frame * a.out.frame_stride + (size_t)ox * sizeof(texel_t);
-  // :324-326 (x part, shared by this lane's 4 rows)
+  // :324-326 (x part, shared by this lane's rows)
   float ppx = (float)ox * c0x + c0z;
   const float fpx = floorf(ppx);
   ppx -= fpx;
   const int lx = (int)fpx - fx0;  // footprint column of texel 'f'
-  const bool hdr = (a.flags & FSR1_FLAG_HDR_SQUARE) != 0;
+  // `c *= c` (FSR_Pass.hlsl:78-79) is a template parameter of the plain kernels (a run-time flag costs three multiplies
+  // and three selects per pixel for an option only the EASU-only HDR path uses); the colour variants read the flag
+  const bool hdr = COLOR ? (a.flags & FSR1_FLAG_HDR_SQUARE) != 0 : HDR;
 
 #pragma unroll 1
   for (int r = 0; r < kTileH / 4; ++r) {
@@ -104,27 +112,24 @@ __global__ void __launch_bounds__(kThreads) easu_kernel(const EasuArgs a) {
     ppy -= fpy;
     const int f_idx = ((int)fpy - fy0) * fw + lx;
     const rgbf_t p = easu_pixel<EXACT>(l, f_idx, ppx, ppy);
+    const EasuBounds m = easu_bounds(l, f_idx);
     texel_t* const dst = reinterpret_cast<texel_t*>(out_col + (long long)oy * a.out.pitch);
     if constexpr (COLOR) {
-      rgbf_t q = easu_resolve_f(l, f_idx, p, hdr);
+      rgbf_t q = easu_clamp<EXACT>(m, p, hdr);
       color_epilogue<EXACT>(a.color, (uint32_t)ox, (uint32_t)oy, q.r, q.g, q.b);
       *dst = Pixel<FOUT>::store(q.r, q.g, q.b, 1.0f);
     } else {
-      *dst = easu_resolve<FMT, EXACT>(l, f_idx, p, hdr);
+      *dst = easu_resolve<FMT, EXACT>(m, p, hdr);
     }
   }
 }
 
-template <int FMT, bool EXACT, bool COLOR, int FOUT, bool S2 = false>
+template <int FMT, bool EXACT, bool COLOR, int FOUT, bool S2 = false, bool HDR = false>
 hipError_t easu_launch_one(const EasuArgs& a, hipStream_t stream) {
   const dim3 grid((unsigned)(a.tiles_x * a.tiles_y * a.frames)), block(kThreads);
   const size_t lds = easu_lds_bytes(FMT, a.fp_w, a.fp_h);
-  if (lds > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&easu_kernel<FMT, EXACT, COLOR, FOUT, S2>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-  }
-  hipLaunchKernelGGL((easu_kernel<FMT, EXACT, COLOR, FOUT, S2>), grid, block, lds, stream, a);
+  if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&easu_kernel<FMT, EXACT, COLOR, FOUT, S2, HDR>), lds); e != hipSuccess) return e;
+  hipLaunchKernelGGL((easu_kernel<FMT, EXACT, COLOR, FOUT, S2, HDR>), grid, block, lds, stream, a);
   return hipGetLastError();
 }
 

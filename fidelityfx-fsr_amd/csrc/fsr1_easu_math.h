@@ -2,23 +2,23 @@
 // EASU->RCAS kernel: footprint staging (phases 1-2) and the per-pixel filter (phase 3).
 //
 // MI355X cost model that shaped them (tools/ubench/ubench2.hip, measured): v_fma/v_mul/v_add_f32
-// issue at ~2.4 cycles per wave64 instruction, while v_min/v_max/v_cvt/v_fma_mix and every packed
+// issue at ~2.4 cycles per wave64 instruction, while v_min/v_max/v_cvt/v_fma_mix, integer and every packed
 // (v_pk_*) instruction take ~4.3 and v_rcp/v_rsq ~8.5.  So: fp32 texels in LDS (no per-tap
 // conversions), plain v_fma_f32 everywhere, the window clip done by the free `clamp` modifier
-// instead of v_min_f32, min/max hoisted to the per-texel phase.
+// instead of v_min_f32, and a staging pass that spends as few of the expensive integer / convert / min-max
+// instructions per texel as it can (round 2: staging was a fifth of the kernel's issue time).
 #pragma once
 #include "fsr1_color_math.h"
 #include "fsr1_device.h"
 
 namespace fsr1 {
 
-// LDS bytes per footprint texel: fp32 texel (R,G,B,luma) + analysis + dering bounds
-constexpr int kEasuLdsPerTexel = 16 + 16 + 16;
+// LDS bytes per footprint texel: fp32 texel (R,G,B,luma*2) + analysis
+constexpr int kEasuLdsPerTexel = 16 + 16;
 
 struct EasuLds {
   float4_t* tex;  // [n] R G B luma*2
-  float4_t* ana;  // [n] dirX dirY lenX^2 lenY^2 of FsrEasuSetF for the '+' around the texel
-  uint4* mm;      // [n] RGBA16F only: packed binary16 min.RG min.B1 max.RG max.B1 of the 2x2 block at the texel
+  float4_t* ana;  // [n] FsrEasuSetF terms of the '+' around the texel: dirX dirY lenX^2 lenY^2 (EXACT) / dirX dirY lenX^2+lenY^2 - (default)
   int fw;         // row pitch (texels) = footprint width; arrays are dense
 };
 
@@ -26,46 +26,63 @@ __device__ __forceinline__ EasuLds easu_lds_carve(char* smem, int capacity_texel
   EasuLds l;
   l.tex = reinterpret_cast<float4_t*>(smem);
   l.ana = reinterpret_cast<float4_t*>(smem + (size_t)capacity_texels * 16);
-  l.mm = reinterpret_cast<uint4*>(smem + (size_t)capacity_texels * 32);
   l.fw = 0;
   return l;
 }
 
 // Phases 1 and 2 for the footprint [fx0, fx0+fw) x [fy0, fy0+fh) of input texels (unclamped
 // coordinates; the sampler's clamp-to-edge, FSR_Filter.cpp:48-53, is applied while loading).
-// Ends with a barrier: afterwards every thread may read any footprint entry.
-// PRE: the colour prologue (FsrSrtmF, fsr1_color_math.h) is applied to every texel as it is loaded — the texels in
-// LDS are then arbitrary binary32 values, so the packed binary16 dering bounds are not used (easu_resolve).
-template <int FMT, bool PRE = false, bool EXACT = false>
+// Ends with a barrier: afterwards every thread may read any footprint entry that a 12-tap window can touch
+// (the bottom-right corner texel of the footprint is touched by none — no window has a (2, 2) tap — and is not staged:
+// at exactly 2x that makes the 35 x 11 footprint 384 texels = six full wave-iterations instead of six and one lane).
+// PRE: the colour prologue (FsrSrtmF, fsr1_color_math.h) is applied to every texel as it is loaded.
+// FW, FH: compile-time footprint extent (the exact-2x variant: every tile has the same one), 0 = run-time.
+// The host guarantees fh * pitch < 2^31 (fsr1_api.hip), so texel addresses are a wave-uniform 64-bit row base plus a
+// 32-bit lane offset (global_load ... v_off, s[base]: no 64-bit vector arithmetic).
+template <int FMT, bool PRE = false, bool EXACT = false, int FW = 0, int FH = 0>
 __device__ __forceinline__ void easu_stage_footprint(const EasuLds& l, const ImageView& in, const char* in_frame, int fx0, int fy0,
-                                                     int fw, int fh, int tid, const ColorArgs* color = nullptr) {
+                                                     int fw_rt, int fh_rt, int tid, const ColorArgs* color = nullptr) {
   typedef typename Pixel<FMT>::T texel_t;
-  const int n = fw * fh;
+  const int fw = FW ? FW : fw_rt, fh = FH ? FH : fh_rt;
+  const int n = fw * fh - 1;
   const float inv_fw = 1.0f / (float)fw;
+  auto row_of = [&](int i) { return FW ? i / FW : (int)(((float)i + 0.5f) * inv_fw); };  // exact for the few thousand texels of a footprint
   // ---- phase 1: HBM -> LDS, one coalesced pass, fp32 once per input texel ----
-  for (int i = tid; i < n; i += kThreads) {
-    const int ly = (int)(((float)i + 0.5f) * inv_fw);  // exact for the few thousand texels of a footprint
-    const int lx = i - ly * fw;
-    const int gy = min(max(fy0 + ly, 0), in.height - 1);
-    const int gx = min(max(fx0 + lx, 0), in.width - 1);
-    const texel_t px = *reinterpret_cast<const texel_t*>(in_frame + (long long)gy * in.pitch + (size_t)gx * sizeof(texel_t));
+  const int gy0 = min(max(fy0, 0), in.height - 1);  // first row the footprint reads
+  const char* const base = in_frame + (long long)gy0 * in.pitch;
+  const uint32_t pitch = (uint32_t)in.pitch;
+  auto stage = [&](int i, uint32_t off) {
+    const texel_t px = *reinterpret_cast<const texel_t*>(base + (size_t)off);
     float4_t c = Pixel<FMT>::load(px);
     if constexpr (PRE) c = color_prologue<EXACT>(*color, c);
     // :363-366  luma*2 = B*0.5 + (R*0.5 + G); the products by 0.5 are exact, so fusing them is too
     l.tex[i] = float4_t{c.x, c.y, c.z, fmaf(c.z, 0.5f, fmaf(c.x, 0.5f, c.y))};
+  };
+  if (fx0 >= 0 && fy0 >= 0 && fx0 + fw <= in.width && fy0 + fh <= in.height) {  // wave-uniform: nothing to clamp (all tiles but the image's border)
+    const uint32_t x_off = (uint32_t)fx0 * (uint32_t)sizeof(texel_t);
+    for (int i = tid; i < n; i += kThreads) {
+      const int ly = row_of(i);
+      stage(i, (uint32_t)ly * pitch + (uint32_t)(i - ly * fw) * (uint32_t)sizeof(texel_t) + x_off);
+    }
+  } else {
+    for (int i = tid; i < n; i += kThreads) {
+      const int ly = row_of(i);
+      const int gy = min(max(fy0 + ly, 0), in.height - 1);
+      const int gx = min(max(fx0 + (i - ly * fw), 0), in.width - 1);
+      stage(i, (uint32_t)(gy - gy0) * pitch + (uint32_t)gx * (uint32_t)sizeof(texel_t));
+    }
   }
   __syncthreads();
-  // ---- phase 2: per-texel terms, for the texels that are read as f/g/j/k of some pixel: columns 1..fw-2, rows
-  //      1..fh-2 of the footprint (every neighbour of those lies inside it, so nothing is clamped). ----
+  // ---- phase 2: FsrEasuSetF's per-position terms, for the texels that are read as f/g/j/k of some pixel: columns
+  //      1..fw-2, rows 1..fh-2 of the footprint (every neighbour of those lies inside it, so nothing is clamped). ----
   const int iw = fw - 2, m = iw * (fh - 2);
   const float inv_iw = 1.0f / (float)iw;
+  const float* const lum = reinterpret_cast<const float*>(l.tex) + 3;  // luma of texel i at lum[4 * i]
   for (int j = tid; j < m; j += kThreads) {
-    const int y = (int)(((float)j + 0.5f) * inv_iw);
+    const int y = FW ? j / (FW - 2) : (int)(((float)j + 0.5f) * inv_iw);
     const int i = (y + 1) * fw + (j - y * iw) + 1;
-    const int iu = i - fw, id = i + fw, il = i - 1, ir = i + 1;
-    const float4_t tc = l.tex[i], tr = l.tex[ir], td = l.tex[id];
     // FsrEasuSetF :295-313 — reference order, no contraction
-    const float lA = l.tex[iu].w, lB = l.tex[il].w, lC = tc.w, lD = tr.w, lE = td.w;
+    const float lA = lum[4 * (i - fw)], lB = lum[4 * (i - 1)], lC = lum[4 * i], lD = lum[4 * (i + 1)], lE = lum[4 * (i + fw)];
     const float dc = lD - lC, cb = lC - lB;
     float lenX = APrxLoRcpF1(fmaxf(fabsf(dc), fabsf(cb)));
     const float dirX = lD - lB;
@@ -76,20 +93,9 @@ __device__ __forceinline__ void easu_stage_footprint(const EasuLds& l, const Ima
     const float dirY = lE - lA;
     lenY = sat(fabsf(dirY) * lenY);
     lenY *= lenY;
-    l.ana[i] = float4_t{dirX, dirY, lenX, lenY};
-    if (FMT == FSR1_FORMAT_RGBA16F && !PRE) {
-      // :416-419 min/max over the 2x2 block whose top-left texel is i (f g / j k).  The texels are binary16
-      // values, so their min/max are too: keep them packed and clamp after the final rounding (rounding is
-      // monotone, the bounds are representable, so both orders give the same binary16).  .w = 1 forces alpha.
-      const float4_t tdr = l.tex[id + 1];
-      const float mnR = fminf(min3f(tc.x, tr.x, td.x), tdr.x), mxR = fmaxf(max3f(tc.x, tr.x, td.x), tdr.x);
-      const float mnG = fminf(min3f(tc.y, tr.y, td.y), tdr.y), mxG = fmaxf(max3f(tc.y, tr.y, td.y), tdr.y);
-      const float mnB = fminf(min3f(tc.z, tr.z, td.z), tdr.z), mxB = fmaxf(max3f(tc.z, tr.z, td.z), tdr.z);
-      const half2_t a0 = {(half_t)mnR, (half_t)mnG}, a1 = {(half_t)mnB, (half_t)1.0f};
-      const half2_t b0 = {(half_t)mxR, (half_t)mxG}, b1 = {(half_t)mxB, (half_t)1.0f};
-      l.mm[i] = uint4{__builtin_bit_cast(uint32_t, a0), __builtin_bit_cast(uint32_t, a1), __builtin_bit_cast(uint32_t, b0),
-                      __builtin_bit_cast(uint32_t, b1)};
-    }
+    // `len` is continuous in its inputs and does not feed the zero test: the default arithmetic adds the two squares
+    // here, once per texel, instead of once per pixel and position (easu_pixel)
+    l.ana[i] = EXACT ? float4_t{dirX, dirY, lenX, lenY} : float4_t{dirX, dirY, lenX + lenY, 0.0f};
   }
   __syncthreads();
 }
@@ -114,11 +120,16 @@ __device__ __forceinline__ rgbf_t easu_pixel(const EasuLds& l, int f_idx, float 
   dirx += aj.x * wU; diry += aj.y * wU;
   dirx += ak.x * wV; diry += ak.y * wV;
   float len = af.z * wS;
-  // len does not feed the zero test, so outside EXACT its multiply-adds are fused
-  len = mad<EXACT>(af.w, wS, len);
-  len = mad<EXACT>(ag.z, wT, len); len = mad<EXACT>(ag.w, wT, len);
-  len = mad<EXACT>(aj.z, wU, len); len = mad<EXACT>(aj.w, wU, len);
-  len = mad<EXACT>(ak.z, wV, len); len = mad<EXACT>(ak.w, wV, len);
+  if (EXACT) {
+    len = af.w * wS + len;
+    len = ag.z * wT + len; len = ag.w * wT + len;
+    len = aj.z * wU + len; len = aj.w * wU + len;
+    len = ak.z * wV + len; len = ak.w * wV + len;
+  } else {  // .z already holds lenX^2 + lenY^2
+    len = fmaf(ag.z, wT, len);
+    len = fmaf(aj.z, wU, len);
+    len = fmaf(ak.z, wV, len);
+  }
 
   // :389-395 normalise; the zero test is the filter's only branch-like discontinuity
   const float dir2x = dirx * dirx, dir2y = diry * diry;
@@ -176,57 +187,80 @@ __device__ __forceinline__ rgbf_t easu_pixel(const EasuLds& l, int f_idx, float 
     const float sm = q01 * oym, s0 = q01 * oy0, s1 = q01 * oy1, s2 = q01 * oy2;
     const float bm = q11 * (oym * oym), b0 = q11 * (oy0 * oy0), b1 = q11 * (oy1 * oy1), b2 = q11 * (oy2 * oy2);
     const float k2 = 0.25f * clp * clp, k1 = -1.25f * clp, k3 = lob * clp;
-    auto tap = [&](int dx, int dy, float ox, float s, float b) {
-      const float4_t c = l.tex[f_idx + dy * fw + dx];
+    auto weight = [&](float ox, float s, float b) {
       const float u = sat(fmaf(ox, fmaf(q00, ox, s), b));
       const float base = fmaf(fmaf(k2, u, k1), u, 1.0f);
       const float wa = fmaf(k3, u, -1.0f);
-      const float w = base * (wa * wa);
+      return base * (wa * wa);
+    };
+    auto tap = [&](int dx, int dy, float ox, float s, float b) {
+      const float4_t c = l.tex[f_idx + dy * fw + dx];
+      const float w = weight(ox, s, b);
       aR = fmaf(c.x, w, aR); aG = fmaf(c.y, w, aG); aB = fmaf(c.z, w, aB);
       aW += w;
     };
-    tap(0, -1, ox0, sm, bm); tap(1, -1, ox1, sm, bm);
+    {  // the first tap starts the sums
+      const float4_t c = l.tex[f_idx - fw];
+      aW = weight(ox0, sm, bm);
+      aR = c.x * aW; aG = c.y * aW; aB = c.z * aW;
+    }
+    tap(1, -1, ox1, sm, bm);
     tap(-1, 0, oxm, s0, b0); tap(0, 0, ox0, s0, b0); tap(1, 0, ox1, s0, b0); tap(2, 0, ox2, s0, b0);
     tap(-1, 1, oxm, s1, b1); tap(0, 1, ox0, s1, b1); tap(1, 1, ox1, s1, b1); tap(2, 1, ox2, s1, b1);
     tap(0, 2, ox0, s2, b2); tap(1, 2, ox1, s2, b2);
   }
-  // :437 normalise (dering clamp is applied by the caller, in the storage format)
+  // :437 normalise (dering clamp is applied by the caller)
   const float rW = EXACT ? 1.0f / aW : __builtin_amdgcn_rcpf(aW);
   // pinned in every variant: the narrowing that follows must round the binary32 product, not re-fuse it
   // (v_fma_mixlo_f16), or two kernels sharing this code could round the same pixel differently
   return rgbf_t{pinned(aR * rW), pinned(aG * rW), pinned(aB * rW)};
 }
 
-// Dering clamp (:416-419, :437) + alpha = 1 (FSR_Pass.hlsl:80) + optional `c *= c` (FSR_Pass.hlsl:78-79),
-// producing the pixel in its storage format.
-// Dering clamp in binary32 (:416-419, :437) + optional `c *= c`: the filter's result before the store conversion.
-__device__ __forceinline__ rgbf_t easu_resolve_f(const EasuLds& l, int f_idx, rgbf_t p, bool hdr_square) {
+// Dering bounds (:416-419): per-channel min and max of the 2x2 block f g / j k whose top-left texel is f_idx.
+// v_min3_f32 / v_max3_f32 written out: the operands come straight from LDS, where the compiler no longer knows they are
+// canonical and would spend a `v_max_f32 x, x, x` on each of the twelve before handing them to fminf / fmaxf; the
+// instructions themselves are IEEE minNum / maxNum, which is the oracle's pin for the shading languages' min / max.
+struct EasuBounds { float mnR, mnG, mnB, mxR, mxG, mxB; };
+
+__device__ __forceinline__ float min4_asm(float a, float b, float c, float d) {
+  float t;
+  asm("v_min3_f32 %0, %1, %2, %3\n\tv_min_f32 %0, %0, %4" : "=&v"(t) : "v"(a), "v"(b), "v"(c), "v"(d));
+  return t;
+}
+__device__ __forceinline__ float max4_asm(float a, float b, float c, float d) {
+  float t;
+  asm("v_max3_f32 %0, %1, %2, %3\n\tv_max_f32 %0, %0, %4" : "=&v"(t) : "v"(a), "v"(b), "v"(c), "v"(d));
+  return t;
+}
+
+__device__ __forceinline__ EasuBounds easu_bounds(const EasuLds& l, int f_idx) {
   const int fw = l.fw;
   const float4_t cf = l.tex[f_idx], cg = l.tex[f_idx + 1], cj = l.tex[f_idx + fw], ck = l.tex[f_idx + fw + 1];
-  float pr = fminf(fmaxf(max3f(cf.x, cg.x, cj.x), ck.x), fmaxf(fminf(min3f(cf.x, cg.x, cj.x), ck.x), p.r));
-  float pg = fminf(fmaxf(max3f(cf.y, cg.y, cj.y), ck.y), fmaxf(fminf(min3f(cf.y, cg.y, cj.y), ck.y), p.g));
-  float pb = fminf(fmaxf(max3f(cf.z, cg.z, cj.z), ck.z), fmaxf(fminf(min3f(cf.z, cg.z, cj.z), ck.z), p.b));
+  return EasuBounds{min4_asm(cf.x, cg.x, cj.x, ck.x), min4_asm(cf.y, cg.y, cj.y, ck.y), min4_asm(cf.z, cg.z, cj.z, ck.z),
+                    max4_asm(cf.x, cg.x, cj.x, ck.x), max4_asm(cf.y, cg.y, cj.y, ck.y), max4_asm(cf.z, cg.z, cj.z, ck.z)};
+}
+
+// Dering clamp in binary32 (:437 `min(max4, max(min4, pix))`) + optional `c *= c` (FSR_Pass.hlsl:78-79): the filter's
+// result before the store conversion.  Clamping before or after the store's rounding gives the same stored value: rounding
+// is monotone and the bounds are values of the storage format.  EXACT keeps the reference's two operations; the default
+// arithmetic takes v_med3_f32, which returns min3 of its operands when one is a NaN — what max-then-min returns too
+// when `pix` is the NaN (a window whose weights sum to zero).
+template <bool EXACT>
+__device__ __forceinline__ rgbf_t easu_clamp(const EasuBounds& m, rgbf_t p, bool hdr_square) {
+  float pr, pg, pb;
+  if (EXACT) {
+    pr = fminf(m.mxR, fmaxf(m.mnR, p.r)); pg = fminf(m.mxG, fmaxf(m.mnG, p.g)); pb = fminf(m.mxB, fmaxf(m.mnB, p.b));
+  } else {
+    pr = __builtin_amdgcn_fmed3f(p.r, m.mnR, m.mxR); pg = __builtin_amdgcn_fmed3f(p.g, m.mnG, m.mxG); pb = __builtin_amdgcn_fmed3f(p.b, m.mnB, m.mxB);
+  }
   if (hdr_square) { pr *= pr; pg *= pg; pb *= pb; }
   return rgbf_t{pinned(pr), pinned(pg), pinned(pb)};
 }
 
-template <int FMT, bool EXACT, bool PRE = false>
-__device__ __forceinline__ typename Pixel<FMT>::T easu_resolve(const EasuLds& l, int f_idx, rgbf_t p, bool hdr_square) {
-  typedef typename Pixel<FMT>::T texel_t;
-  if constexpr (FMT == FSR1_FORMAT_RGBA16F && !PRE) if (!hdr_square) {
-    const uint4 mm = l.mm[f_idx];
-    half2_t rg = __builtin_convertvector(float2_t{p.r, p.g}, half2_t);  // v_cvt_pk_f16_f32, RTNE
-    half2_t b1 = __builtin_convertvector(float2_t{p.b, 1.0f}, half2_t);
-    // v_pk_max_f16 / v_pk_min_f16 written out: through the builtins the compiler first canonicalises the four bounds
-    // it loaded from LDS (v_pk_max_f16 x, x, x each — it cannot know they were produced by a conversion), which
-    // doubles the half-rate instructions of this clamp; the instructions themselves are IEEE maxNum/minNum.
-    uint32_t rgu = __builtin_bit_cast(uint32_t, rg), b1u = __builtin_bit_cast(uint32_t, b1);
-    asm("v_pk_max_f16 %0, %1, %0\n\tv_pk_min_f16 %0, %2, %0" : "+v"(rgu) : "v"(mm.x), "v"(mm.z));
-    asm("v_pk_max_f16 %0, %1, %0\n\tv_pk_min_f16 %0, %2, %0" : "+v"(b1u) : "v"(mm.y), "v"(mm.w));
-    const uint2 packed = {rgu, b1u};
-    return __builtin_bit_cast(texel_t, packed);
-  }
-  const rgbf_t q = easu_resolve_f(l, f_idx, p, hdr_square);
+// Dering clamp + alpha = 1 (FSR_Pass.hlsl:80), producing the pixel in its storage format.
+template <int FMT, bool EXACT>
+__device__ __forceinline__ typename Pixel<FMT>::T easu_resolve(const EasuBounds& m, rgbf_t p, bool hdr_square) {
+  const rgbf_t q = easu_clamp<EXACT>(m, p, hdr_square);
   return Pixel<FMT>::store(q.r, q.g, q.b, 1.0f);
 }
 

@@ -58,7 +58,7 @@ __global__ void __launch_bounds__(kThreads) fused_kernel(const FusedArgs a) {
       const float fpy = floorf(ppy);
       ppy -= fpy;
       const int f_idx = ((int)fpy - fy0) * fw + lxf;
-      px = easu_resolve<FMT, EXACT, COLOR>(l, f_idx, easu_pixel<EXACT>(l, f_idx, ppx, ppy), false);
+      px = easu_resolve<FMT, EXACT>(easu_bounds(l, f_idx), easu_pixel<EXACT>(l, f_idx, ppx, ppy), false);
     }
     mid[my * kMidW + mx] = px;
   };
@@ -125,11 +125,7 @@ template <int FMT, bool EXACT, bool COLOR, int FOUT>
 hipError_t fused_launch_one(const FusedArgs& a, hipStream_t stream) {
   const dim3 grid((unsigned)(a.tiles_x * a.tiles_y * a.frames)), block(kThreads);
   const size_t lds = fused_lds_bytes(FMT, a.fp_w, a.fp_h);
-  if (lds > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_kernel<FMT, EXACT, COLOR, FOUT>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-  }
+  if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&fused_kernel<FMT, EXACT, COLOR, FOUT>), lds); e != hipSuccess) return e;
   hipLaunchKernelGGL((fused_kernel<FMT, EXACT, COLOR, FOUT>), grid, block, lds, stream, a);
   return hipGetLastError();
 }

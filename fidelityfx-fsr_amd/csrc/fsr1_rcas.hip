@@ -16,6 +16,9 @@
 //   * texels outside the image are 0 (the D3D `Load` rule of the reference's callback, FSR_Pass.hlsl:45,61).
 #include "fsr1_rcas_kernel.h"
 
+#ifndef FSR1_RCAS_SHALLOW_RING
+#define FSR1_RCAS_SHALLOW_RING 2
+#endif
 namespace fsr1 {
 
 // Strip height.  Measured on MI355X at 3840x2160 (gpurun_out/): the pass runs at the same ~34 us for
@@ -44,7 +47,7 @@ hipError_t rcas_launch(const RcasArgs& a, int fmt, bool exact, hipStream_t strea
   const bool shallow = (long long)a.tiles_x * ((a.in.height + 15) / 16) * a.frames * kRcasWaves < 6LL * 4 * 256;
 #define FSR1_RCAS(F, E, O)                                                                                                                  \
   do {                                                                                                                                      \
-    if (shallow) hipLaunchKernelGGL((rcas_kernel<F, E, O, false, F, (F == FSR1_FORMAT_RGBA32F ? 4 : 2)>), grid, block, 0, stream, a);       \
+    if (shallow) hipLaunchKernelGGL((rcas_kernel<F, E, O, false, F, (F == FSR1_FORMAT_RGBA32F ? 4 : FSR1_RCAS_SHALLOW_RING)>), grid, block, 0, stream, a);       \
     else hipLaunchKernelGGL((rcas_kernel<F, E, O, false, F, (F == FSR1_FORMAT_RGBA32F ? 4 : kRcasRing)>), grid, block, 0, stream, a);       \
   } while (0)
 #define FSR1_RCAS_O(F, E) do { if (opts) FSR1_RCAS(F, E, true); else FSR1_RCAS(F, E, false); } while (0)

@@ -34,7 +34,10 @@ template <> struct RcasPair<FSR1_FORMAT_R10G10B10A2_UNORM> { typedef uint32_t T 
 // image, so nothing is predicated except the apron load of lanes 0 / 63.
 // COLOR: colour stages fused in (fsr1_color_math.h) — FsrSrtmF on every tap as it is loaded (the role of the
 // FsrRcasInputF callback, ffx_fsr1.h:682), FsrLfgaF / FsrSrtmInvF / FsrTepdC*F on the result before it is stored as FOUT.
-template <int FMT, bool EXACT, bool OPTS, bool INTERIOR, bool COLOR, int FOUT, int RING>
+// UP: the strip is walked from its last row to its first (interior strips only).  Vertically adjacent strips walk in
+// opposite directions, so the two apron rows they share are read by both at the same end of their lives — close in
+// time, the second reader from L2 — instead of ~a kernel duration apart.
+template <int FMT, bool EXACT, bool OPTS, bool INTERIOR, bool COLOR, int FOUT, int RING, bool UP = false>
 __device__ __forceinline__ void rcas_strip(const RcasArgs& a, int frame, int x0, int y0, int lane) {
   typedef typename Pixel<FMT>::T texel_t;
   typedef typename RcasPair<FMT>::T pair_t;
@@ -53,6 +56,8 @@ __device__ __forceinline__ void rcas_strip(const RcasArgs& a, int frame, int x0,
   const char* const in_hcol = a.in.base + (long long)frame * a.in.frame_stride + (size_t)hcol * sizeof(texel_t);
   char* const out_col = a.out.base + (long long)frame * a.out.frame_stride + (size_t)col * sizeof(out_t);
 
+  const int rows = a.rows;
+  auto row_y = [&](int k) { return UP ? y0 + rows - 1 - k : y0 + k; };  // k-th row of the walk, k = -1 .. rows
   struct row_t { texel_t p0, p1, halo; };
   auto load = [&](int y, row_t& r) {
     if (!INTERIOR) r.halo = Pixel<FMT>::zero();
@@ -99,22 +104,20 @@ __device__ __forceinline__ void rcas_strip(const RcasArgs& a, int frame, int x0,
   rgb_t prev0, prev1, cur0, cur1;
   {
     row_t q_prev;
-    load(y0 - 1, q_prev);
+    load(row_y(-1), q_prev);
 #pragma unroll
-    for (int k = 0; k < kAhead; ++k) load(y0 + k, q[k]);
+    for (int k = 0; k < kAhead; ++k) load(row_y(k), q[k]);
     prev0 = rgb(q_prev.p0); prev1 = rgb(q_prev.p1);
     cur0 = rgb(q[0].p0); cur1 = rgb(q[0].p1);
   }
   const float sharp = as_f32(a.con[0]);
-  const int rows = a.rows;
-  const int y_last = y0 + rows;  // the row below the strip is the last one read
 
 #pragma unroll 1
   for (int r0 = 0; r0 < rows; r0 += kRing) {
 #pragma unroll
     for (int k = 0; k < kRing; ++k) {
-      const int y = y0 + r0 + k;
-      load(min(y + kAhead, y_last), q[(k + kAhead) % kRing]);  // past the end: re-reads the last row (harmless, branch-free)
+      const int y = row_y(r0 + k);
+      load(row_y(min(r0 + k + kAhead, rows)), q[(k + kAhead) % kRing]);  // past the end: re-reads the last row (harmless, branch-free)
       const row_t& c = q[k];
       const row_t& n = q[(k + 1) % kRing];
       const rgb_t next0 = rgb(n.p0), next1 = rgb(n.p1);
@@ -126,8 +129,11 @@ __device__ __forceinline__ void rcas_strip(const RcasArgs& a, int frame, int x0,
       rgb_t o0 = {prev0.r + d0.r, cur0.g + next0.g, cur1.b}, o1 = {prev1.r + f1.r, cur1.g + next1.g, cur0.b};
       (void)sharp;
 #else
-      rgb_t o0 = rcas_pixel<EXACT>(known(prev0), d0, known(cur0), known(cur1), next0, sharp, flags);
-      rgb_t o1 = rcas_pixel<EXACT>(known(prev1), known(cur0), known(cur1), f1, next1, sharp, flags);
+      // b is the tap above, h the one below (ffx_fsr1.h:697-707): when walking up, `prev` is the row below
+      rgb_t o0 = UP ? rcas_pixel<EXACT>(next0, d0, known(cur0), known(cur1), known(prev0), sharp, flags)
+                    : rcas_pixel<EXACT>(known(prev0), d0, known(cur0), known(cur1), next0, sharp, flags);
+      rgb_t o1 = UP ? rcas_pixel<EXACT>(next1, known(cur0), known(cur1), f1, known(prev1), sharp, flags)
+                    : rcas_pixel<EXACT>(known(prev1), known(cur0), known(cur1), f1, next1, sharp, flags);
 #endif
       if (INTERIOR || y < H) {
         const bool alpha = (flags & FSR1_FLAG_RCAS_PASSTHROUGH_ALPHA) != 0;  // :700-705 / FSR_Pass.hlsl:94
@@ -168,6 +174,10 @@ __global__ void __launch_bounds__(kRcasThreads) rcas_kernel(const RcasArgs a) {
   const int x0 = tx * kRcasCols + wave * kRcasWaveCols, y0 = ty * a.rows;
   if (x0 >= a.in.width) return;  // whole wave outside (no barriers in this kernel)
   const bool interior = x0 >= 1 && x0 + kRcasWaveCols + 1 <= a.in.width && y0 >= 1 && y0 + a.rows + 1 <= a.in.height;
+#ifdef FSR1_RCAS_ALTERNATE
+  if (interior && (ty & 1)) rcas_strip<FMT, EXACT, OPTS, true, COLOR, FOUT, RING, true>(a, frame, x0, y0, lane);
+  else
+#endif
   if (interior) rcas_strip<FMT, EXACT, OPTS, true, COLOR, FOUT, RING>(a, frame, x0, y0, lane);
   else rcas_strip<FMT, EXACT, OPTS, false, COLOR, FOUT, RING>(a, frame, x0, y0, lane);
 }

@@ -1,0 +1,108 @@
+#!/usr/bin/env python3
+"""A/B timing of library variants on the GPU box (tuning tool, not the bench contract).
+
+  python tools/abtest.py --libs variants/a.so,variants/b.so --workloads 1080p_to_4k,1440p_to_4k --reps 3
+
+Each variant runs in its own process (FSR1_HIP_LIB selects the library); per workload it prints one line with the
+HIP-event time per launch (C-ABI stopwatch on the launch stream) of EASU, RCAS on a cold ring, the two-dispatch pair,
+and the fused launch.  Variants are interleaved `reps` times so that box-to-box / thermal drift shows as spread
+between repetitions rather than as a difference between variants.
+"""
+import argparse
+import importlib
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def child(args):
+    import numpy as np
+    import torch
+    import bench
+    fsr = importlib.import_module("fidelityfx-fsr_amd")
+    fsr.load()
+    dev = torch.device("cuda", 0)
+    flags = {"f": 0, "exact": fsr.FLAG_MATH_EXACT, "h": fsr.FLAG_MATH_PACKED_FP16}[args.math]
+    if args.no_fast_paths:
+        flags |= fsr.FLAG_NO_FAST_PATHS
+    timer = fsr.Timer()
+    for wl in args.workloads.split(","):
+        in_w, in_h, out_w, out_h, frames = bench.WORKLOADS[wl]
+        set_bytes = (in_w * in_h + 2 * out_w * out_h) * 8 * frames
+        ring = max(2, -(-320 * 2**20 // set_bytes))
+        base = torch.from_numpy(fsr.frames.synthetic_frame(in_w, in_h, k=1)).to(dev)
+        srcs = [torch.stack([torch.roll(base, shifts=(3 * s + f, 5 * s + 2 * f), dims=(0, 1)) for f in range(frames)]).contiguous() for s in range(ring)]
+        mids = [torch.empty(frames, out_h, out_w, 4, dtype=torch.float16, device=dev) for _ in range(ring)]
+        dsts = [torch.empty(frames, out_h, out_w, 4, dtype=torch.float16, device=dev) for _ in range(ring)]
+        econ = fsr.FsrEasuCon(in_w, in_h, in_w, in_h, out_w, out_h)
+        rcon = fsr.FsrRcasCon(0.25)
+        for s in range(ring):
+            fsr.easu(srcs[s], mids[s], con=econ, flags=flags)
+        torch.cuda.synchronize()
+
+        def easu(i): fsr.easu(srcs[i % ring], mids[i % ring], con=econ, flags=flags)
+        def rcas(i): fsr.rcas(mids[i % ring], dsts[i % ring], con=rcon, flags=flags)
+        def pair(i): easu(i); rcas(i)
+        def fused(i): fsr.easu_rcas_fused(srcs[i % ring], dsts[i % ring], easu_con=econ, rcas_con=rcon, flags=flags)
+
+        def ms(fn, n):
+            import time
+            t0 = time.perf_counter()
+            i = 0
+            while time.perf_counter() - t0 < args.ramp:  # clock ramp + steady power state
+                fn(i); i += 1
+                if i % 64 == 0:
+                    torch.cuda.synchronize()
+            torch.cuda.synchronize()
+            timer.start()
+            for i in range(n):
+                fn(i)
+            timer.stop()
+            return timer.elapsed_ms() / n
+
+        n = max(10, int(args.launches / max(1, frames)))
+        row = {"lib": os.path.basename(os.environ.get("FSR1_HIP_LIB", "default")), "workload": wl, "math": args.math}
+        for name, fn in (("easu", easu), ("rcas", rcas), ("pair", pair)) + ((("fused", fused),) if args.math != "h" else ()):
+            if name in args.kernels.split(","):
+                row[name + "_us"] = round(ms(fn, n) * 1e3, 2)
+        print(json.dumps(row), flush=True)
+        del srcs, mids, dsts
+        torch.cuda.empty_cache()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--libs", default="")
+    ap.add_argument("--workloads", default="1080p_to_4k")
+    ap.add_argument("--kernels", default="easu,rcas,pair,fused")
+    ap.add_argument("--math", default="f")
+    ap.add_argument("--no-fast-paths", action="store_true")
+    ap.add_argument("--reps", type=int, default=2)
+    ap.add_argument("--launches", type=int, default=400)
+    ap.add_argument("--ramp", type=float, default=0.25)
+    ap.add_argument("--child", action="store_true")
+    args = ap.parse_args()
+    if args.child:
+        return child(args)
+    libs = [l for l in args.libs.split(",") if l] or [""]
+    for rep in range(args.reps):
+        for lib in libs:
+            env = dict(os.environ)
+            if lib:
+                env["FSR1_HIP_LIB"] = os.path.join(ROOT, lib)
+            cmd = [sys.executable, os.path.abspath(__file__), "--child", "--workloads", args.workloads, "--kernels", args.kernels,
+                   "--math", args.math, "--launches", str(args.launches), "--ramp", str(args.ramp)] + (["--no-fast-paths"] if args.no_fast_paths else [])
+            r = subprocess.run(cmd, env=env, capture_output=True, text=True)
+            for line in r.stdout.splitlines():
+                if line.startswith("{"):
+                    print(line, flush=True)
+            if r.returncode:
+                print(json.dumps({"lib": lib, "error": r.stderr[-400:]}), flush=True)
+
+
+if __name__ == "__main__":
+    main()
