@@ -6,7 +6,7 @@
 // owns a 128-column x 8-row block, a lane two adjacent pixels (one 16-byte access per row for RGBA16F), all eight
 // row loads are issued before the first use; the four waves of a workgroup stack vertically (128 x 32 tile).
 // The noise tile (a few KiB) stays in L2.
-#include "fsr1_color_math.h"
+#include "fsr1_device_color.hpp"
 #include "fsr1_device.h"
 
 namespace fsr1 {

@@ -23,7 +23,7 @@
 // (no contraction): that decision and floor() are the only discontinuities of the filter, so
 // they must see bit-identical inputs.  With EXACT the rest follows the reference order as well and
 // the result is bit-identical to the CPU-evaluated FsrEasuF; without it the continuous remainder
-// is re-associated (see easu_pixel in fsr1_easu_math.h), which moves the fp32 result by ~1e-6 relative.
+// is re-associated (see easu_pixel in fsr1_device_easu.hpp), which moves the fp32 result by ~1e-6 relative.
 #include "fsr1_easu_kernel.h"
 
 namespace fsr1 {

@@ -2,13 +2,13 @@
 // fsr1_easu_color.hip (colour prologue / epilogue variants).
 #pragma once
 #include "fsr1_device.h"
-#include "fsr1_easu_math.h"
+#include "fsr1_device_easu.hpp"
 
 namespace fsr1 {
 
 size_t easu_lds_bytes(int fmt, int fp_w, int fp_h);
 
-// COLOR: colour stages fused in (fsr1_color_math.h) — FsrSrtmF on every input texel as it is loaded, and
+// COLOR: colour stages fused in (fsr1_device_color.hpp) — FsrSrtmF on every input texel as it is loaded, and
 // FsrLfgaF / FsrSrtmInvF / FsrTepdC*F on the result before it is stored as FOUT.  COLOR = false is the plain pass
 // (FOUT == FMT), compiled without any of it.
 //

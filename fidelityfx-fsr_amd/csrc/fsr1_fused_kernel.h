@@ -2,8 +2,8 @@
 // and fsr1_fused_color.hip (colour prologue / epilogue variants).
 #pragma once
 #include "fsr1_device.h"
-#include "fsr1_easu_math.h"
-#include "fsr1_rcas_math.h"
+#include "fsr1_device_easu.hpp"
+#include "fsr1_device_rcas.hpp"
 
 namespace fsr1 {
 
@@ -12,7 +12,7 @@ size_t fused_lds_bytes(int fmt, int fp_w, int fp_h);
 constexpr int kMidW = kTileW + 2;
 constexpr int kMidH = kFusedTileH + 2;
 
-// COLOR: colour stages fused in (fsr1_color_math.h) — FsrSrtmF on every input texel as it is loaded (prologue of
+// COLOR: colour stages fused in (fsr1_device_color.hpp) — FsrSrtmF on every input texel as it is loaded (prologue of
 // EASU), FsrLfgaF / FsrSrtmInvF / FsrTepdC*F on the RCAS result before it is stored as FOUT.  The EASU->RCAS
 // intermediary in LDS keeps the input's format FMT.  COLOR = false is the plain kernel (FOUT == FMT).
 template <int FMT, bool EXACT, bool COLOR = false, int FOUT = FMT>

@@ -11,34 +11,15 @@
 // pixel pair are its own other pixel and the adjacent lane's facing pixel (DPP wave shift); lanes 0 / 63
 // also load the strip's apron column.  Loads outside the image are 0 (FSR_Pass.hlsl:61).
 #include "fsr1_device.h"
+#include "fsr1_device_half.hpp"
 
 namespace fsr1 {
-
-typedef unsigned short u16;
 
 constexpr int kRcasHRows = 24;
 constexpr int kRcasHCols = 128 * 4;  // columns per 256-thread workgroup
 constexpr int kShr1 = 0x138, kShl1 = 0x130;
 
 namespace {
-
-struct soa_t { half2_t r, g, b, a; };  // two pixels: .x = left (even column), .y = right
-
-__device__ __forceinline__ half2_t mx2(half2_t a, half2_t b) { return __builtin_elementwise_max(a, b); }
-__device__ __forceinline__ half2_t mn2(half2_t a, half2_t b) { return __builtin_elementwise_min(a, b); }
-__device__ __forceinline__ half2_t ab2(half2_t a) { return __builtin_elementwise_abs(a); }
-__device__ __forceinline__ half2_t s2(float v) { return half2_t{(half_t)v, (half_t)v}; }
-__device__ __forceinline__ half2_t rcp2(half2_t a) { return half2_t{half_rcp(a.x), half_rcp(a.y)}; }  // ARcpH2: correctly rounded
-// AMin3H2(x,y,z) = min(x, min(y, z)), ffx_a.h:1150 ; AMax3H2 likewise
-__device__ __forceinline__ half2_t mn3(half2_t x, half2_t y, half2_t z) { return mn2(x, mn2(y, z)); }
-__device__ __forceinline__ half2_t mx3(half2_t x, half2_t y, half2_t z) { return mx2(x, mx2(y, z)); }
-// APrxMedRcpH2, ffx_a.h:1816: b = bits(0x778d - bits(a)); b*(-b*a + 2)
-__device__ __forceinline__ half2_t prx_med_rcp2(half2_t a) {
-  typedef u16 u16x2 __attribute__((ext_vector_type(2)));
-  const u16x2 k = {0x778du, 0x778du};
-  const half2_t b = __builtin_bit_cast(half2_t, (u16x2)(k - __builtin_bit_cast(u16x2, a)));
-  return b * (-b * a + s2(2.0f));
-}
 
 template <int CTRL>
 __device__ __forceinline__ half2_t dpp2(half2_t keep, half2_t v) {
@@ -92,8 +73,7 @@ __global__ void __launch_bounds__(kThreads) rcas_h_kernel(const RcasArgs a) {
   }
   // :857 sharpness = AH2_AU1(con.y).x — the packed half of con[1]
   const half_t sharp1 = __builtin_bit_cast(half_t, (u16)(a.con[1] & 0xffffu));
-  const half2_t sharp = {sharp1, sharp1};
-  const half2_t hlf = s2(0.5f), qtr = s2(0.25f), four = s2(4.0f), one = s2(1.0f);
+  const half2_t one = s2(1.0f);
 
 #pragma unroll
   for (int r = 0; r < kRcasHRows; ++r) {
@@ -110,33 +90,8 @@ __global__ void __launch_bounds__(kThreads) rcas_h_kernel(const RcasArgs a) {
     const half2_t fR = {e.r.y, nrR.x}, fG = {e.g.y, nrG.x}, fB = {e.b.y, nrB.x};
     const half2_t bR = b.r, bG = b.g, bB = b.b, eR = e.r, eG = e.g, eB = e.b, hR = h.r, hG = h.g, hB = h.b;
 
-    // :946-951 min and max of ring
-    const half2_t mn4R = mn2(mn3(bR, dR, fR), hR), mn4G = mn2(mn3(bG, dG, fG), hG), mn4B = mn2(mn3(bB, dB, fB), hB);
-    const half2_t mx4R = mx2(mx3(bR, dR, fR), hR), mx4G = mx2(mx3(bG, dG, fG), hG), mx4B = mx2(mx3(bB, dB, fB), hB);
-    // :953-961 limiters (peakC = (1, -4))
-    const half2_t m4 = s2(-4.0f);
-    const half2_t hitMinR = mn2(mn4R, eR) * rcp2(four * mx4R);
-    const half2_t hitMinG = mn2(mn4G, eG) * rcp2(four * mx4G);
-    const half2_t hitMinB = mn2(mn4B, eB) * rcp2(four * mx4B);
-    const half2_t hitMaxR = (one - mx2(mx4R, eR)) * rcp2(four * mn4R + m4);
-    const half2_t hitMaxG = (one - mx2(mx4G, eG)) * rcp2(four * mn4G + m4);
-    const half2_t hitMaxB = (one - mx2(mx4B, eB)) * rcp2(four * mn4B + m4);
-    const half2_t lobeR = mx2(-hitMinR, hitMaxR), lobeG = mx2(-hitMinG, hitMaxG), lobeB = mx2(-hitMinB, hitMaxB);
-    half2_t lobe = mx2(s2(-(0.25f - (1.0f / 16.0f))), mn2(mx3(lobeR, lobeG, lobeB), s2(0.0f))) * sharp;
-    if (flags & FSR1_FLAG_RCAS_DENOISE) {  // :935-944, :969-971
-      const half2_t bL = bB * hlf + (bR * hlf + bG), dL = dB * hlf + (dR * hlf + dG), eL = eB * hlf + (eR * hlf + eG);
-      const half2_t fL = fB * hlf + (fR * hlf + fG), hL = hB * hlf + (hR * hlf + hG);
-      half2_t nz = qtr * bL + qtr * dL + qtr * fL + qtr * hL - eL;
-      nz = mn2(mx2(ab2(nz) * prx_med_rcp2(mx3(mx3(bL, dL, eL), fL, hL) - mn3(mn3(bL, dL, eL), fL, hL)), s2(0.0f)), one);
-      nz = s2(-0.5f) * nz + one;
-      lobe = lobe * nz;
-    }
-    // :973-976 resolve
-    const half2_t rcpL = prx_med_rcp2(four * lobe + one);
-    half2_t pR = (lobe * bR + lobe * dR + lobe * hR + lobe * fR + eR) * rcpL;
-    half2_t pG = (lobe * bG + lobe * dG + lobe * hG + lobe * fG + eG) * rcpL;
-    half2_t pB = (lobe * bB + lobe * dB + lobe * hB + lobe * fB + eB) * rcpL;
-    if (flags & FSR1_FLAG_HDR_SQUARE) { pR = pR * pR; pG = pG * pG; pB = pB * pB; }  // FSR_Pass.hlsl:92-93
+    const rgbh2_t px = rcas_pixel_h2(bR, bG, bB, dR, dG, dB, eR, eG, eB, fR, fG, fB, hR, hG, hB, sharp1, flags);
+    const half2_t pR = px.r, pG = px.g, pB = px.b;
     const half2_t pA = (flags & FSR1_FLAG_RCAS_PASSTHROUGH_ALPHA) ? e.a : one;       // :905-907 / FSR_Pass.hlsl:94
     if (y < H) {
       char* const row = out_frame + (long long)y * a.out.pitch;

@@ -1,9 +1,9 @@
 // RCAS kernel template (see fsr1_rcas.hip for the design notes); instantiated by fsr1_rcas.hip (plain pass) and
 // fsr1_rcas_color.hip (colour prologue / epilogue variants).
 #pragma once
-#include "fsr1_color_math.h"
+#include "fsr1_device_color.hpp"
 #include "fsr1_device.h"
-#include "fsr1_rcas_math.h"
+#include "fsr1_device_rcas.hpp"
 
 namespace fsr1 {
 
@@ -32,7 +32,7 @@ template <> struct RcasPair<FSR1_FORMAT_R10G10B10A2_UNORM> { typedef uint32_t T 
 
 // One 128-column x a.rows strip.  INTERIOR: every texel the strip reads (aprons included) lies inside the
 // image, so nothing is predicated except the apron load of lanes 0 / 63.
-// COLOR: colour stages fused in (fsr1_color_math.h) — FsrSrtmF on every tap as it is loaded (the role of the
+// COLOR: colour stages fused in (fsr1_device_color.hpp) — FsrSrtmF on every tap as it is loaded (the role of the
 // FsrRcasInputF callback, ffx_fsr1.h:682), FsrLfgaF / FsrSrtmInvF / FsrTepdC*F on the result before it is stored as FOUT.
 // UP: the strip is walked from its last row to its first (interior strips only).  Vertically adjacent strips walk in
 // opposite directions, so the two apron rows they share are read by both at the same end of their lives — close in

@@ -8,9 +8,27 @@
 // when EXACT and v_rcp_f32 (1 ulp) otherwise; everything else — including the whole of FsrTepd*F, whose
 // floor() and greater-than-zero test are discontinuities — is evaluated identically in both modes.
 #pragma once
-#include "fsr1_device.h"
+#include "fsr1_device_base.hpp"
 
 namespace fsr1 {
+
+// Arguments of the colour stages (what fsr1_color_stages describes on the host).
+struct NoiseView {
+  const char* base;  // slice already selected (frame % slices) by the host
+  int width, height;
+  long long pitch;
+  int format;        // fsr1_format
+  int off_x, off_y;  // noise_offset reduced to [0, width) x [0, height) by the host
+  float rcp_width, rcp_height;  // 1.0f / width, 1.0f / height (wrap_mod)
+};
+
+struct ColorArgs {
+  uint32_t stages;  // FSR1_COLOR_*
+  float amount, bias;
+  uint32_t frame;
+  NoiseView noise;
+};
+
 
 constexpr uint32_t kColorPrologue = FSR1_COLOR_SRTM;
 constexpr uint32_t kColorEpilogue = FSR1_COLOR_LFGA | FSR1_COLOR_SRTM_INV | FSR1_COLOR_TEPD_C8 | FSR1_COLOR_TEPD_C10;

@@ -8,8 +8,8 @@
 // instead of v_min_f32, and a staging pass that spends as few of the expensive integer / convert / min-max
 // instructions per texel as it can (round 2: staging was a fifth of the kernel's issue time).
 #pragma once
-#include "fsr1_color_math.h"
-#include "fsr1_device.h"
+#include "fsr1_device_base.hpp"
+#include "fsr1_device_color.hpp"
 
 namespace fsr1 {
 
@@ -30,16 +30,37 @@ __device__ __forceinline__ EasuLds easu_lds_carve(char* smem, int capacity_texel
   return l;
 }
 
+// FsrEasuSetF's terms for one position of the '+' neighbourhood  a / b c d / e  (ffx_fsr1.h:295-313), before the
+// bilinear weighting: they depend on the input image only, so the tiled form evaluates them once per input texel.
+// Reference order, no contraction.  Returns (dirX, dirY, lenX^2, lenY^2) when EXACT and (dirX, dirY, lenX^2 + lenY^2, 0)
+// otherwise: `len` is continuous in its inputs and does not feed the zero test, so the default arithmetic adds the two
+// squares here, once per texel, instead of once per pixel and position.
+template <bool EXACT>
+__device__ __forceinline__ float4_t easu_analysis(float lA, float lB, float lC, float lD, float lE) {
+  const float dc = lD - lC, cb = lC - lB;
+  float lenX = APrxLoRcpF1(fmaxf(fabsf(dc), fabsf(cb)));
+  const float dirX = lD - lB;
+  lenX = sat(fabsf(dirX) * lenX);
+  lenX *= lenX;
+  const float ec = lE - lC, ca = lC - lA;
+  float lenY = APrxLoRcpF1(fmaxf(fabsf(ec), fabsf(ca)));
+  const float dirY = lE - lA;
+  lenY = sat(fabsf(dirY) * lenY);
+  lenY *= lenY;
+  return EXACT ? float4_t{dirX, dirY, lenX, lenY} : float4_t{dirX, dirY, lenX + lenY, 0.0f};
+}
+
 // Phases 1 and 2 for the footprint [fx0, fx0+fw) x [fy0, fy0+fh) of input texels (unclamped
 // coordinates; the sampler's clamp-to-edge, FSR_Filter.cpp:48-53, is applied while loading).
 // Ends with a barrier: afterwards every thread may read any footprint entry that a 12-tap window can touch
 // (the bottom-right corner texel of the footprint is touched by none — no window has a (2, 2) tap — and is not staged:
 // at exactly 2x that makes the 35 x 11 footprint 384 texels = six full wave-iterations instead of six and one lane).
-// PRE: the colour prologue (FsrSrtmF, fsr1_color_math.h) is applied to every texel as it is loaded.
+// PRE: the colour prologue (FsrSrtmF, fsr1_device_color.hpp) is applied to every texel as it is loaded.
 // FW, FH: compile-time footprint extent (the exact-2x variant: every tile has the same one), 0 = run-time.
 // The host guarantees fh * pitch < 2^31 (fsr1_api.hip), so texel addresses are a wave-uniform 64-bit row base plus a
 // 32-bit lane offset (global_load ... v_off, s[base]: no 64-bit vector arithmetic).
-template <int FMT, bool PRE = false, bool EXACT = false, int FW = 0, int FH = 0>
+// THREADS: threads of the workgroup, all of which must make the call (it contains two barriers).
+template <int FMT, bool PRE = false, bool EXACT = false, int FW = 0, int FH = 0, int THREADS = 256>
 __device__ __forceinline__ void easu_stage_footprint(const EasuLds& l, const ImageView& in, const char* in_frame, int fx0, int fy0,
                                                      int fw_rt, int fh_rt, int tid, const ColorArgs* color = nullptr) {
   typedef typename Pixel<FMT>::T texel_t;
@@ -60,12 +81,12 @@ __device__ __forceinline__ void easu_stage_footprint(const EasuLds& l, const Ima
   };
   if (fx0 >= 0 && fy0 >= 0 && fx0 + fw <= in.width && fy0 + fh <= in.height) {  // wave-uniform: nothing to clamp (all tiles but the image's border)
     const uint32_t x_off = (uint32_t)fx0 * (uint32_t)sizeof(texel_t);
-    for (int i = tid; i < n; i += kThreads) {
+    for (int i = tid; i < n; i += THREADS) {
       const int ly = row_of(i);
       stage(i, (uint32_t)ly * pitch + (uint32_t)(i - ly * fw) * (uint32_t)sizeof(texel_t) + x_off);
     }
   } else {
-    for (int i = tid; i < n; i += kThreads) {
+    for (int i = tid; i < n; i += THREADS) {
       const int ly = row_of(i);
       const int gy = min(max(fy0 + ly, 0), in.height - 1);
       const int gx = min(max(fx0 + (i - ly * fw), 0), in.width - 1);
@@ -78,41 +99,27 @@ __device__ __forceinline__ void easu_stage_footprint(const EasuLds& l, const Ima
   const int iw = fw - 2, m = iw * (fh - 2);
   const float inv_iw = 1.0f / (float)iw;
   const float* const lum = reinterpret_cast<const float*>(l.tex) + 3;  // luma of texel i at lum[4 * i]
-  for (int j = tid; j < m; j += kThreads) {
+  for (int j = tid; j < m; j += THREADS) {
     const int y = FW ? j / (FW - 2) : (int)(((float)j + 0.5f) * inv_iw);
     const int i = (y + 1) * fw + (j - y * iw) + 1;
-    // FsrEasuSetF :295-313 — reference order, no contraction
-    const float lA = lum[4 * (i - fw)], lB = lum[4 * (i - 1)], lC = lum[4 * i], lD = lum[4 * (i + 1)], lE = lum[4 * (i + fw)];
-    const float dc = lD - lC, cb = lC - lB;
-    float lenX = APrxLoRcpF1(fmaxf(fabsf(dc), fabsf(cb)));
-    const float dirX = lD - lB;
-    lenX = sat(fabsf(dirX) * lenX);
-    lenX *= lenX;
-    const float ec = lE - lC, ca = lC - lA;
-    float lenY = APrxLoRcpF1(fmaxf(fabsf(ec), fabsf(ca)));
-    const float dirY = lE - lA;
-    lenY = sat(fabsf(dirY) * lenY);
-    lenY *= lenY;
-    // `len` is continuous in its inputs and does not feed the zero test: the default arithmetic adds the two squares
-    // here, once per texel, instead of once per pixel and position (easu_pixel)
-    l.ana[i] = EXACT ? float4_t{dirX, dirY, lenX, lenY} : float4_t{dirX, dirY, lenX + lenY, 0.0f};
+    l.ana[i] = easu_analysis<EXACT>(lum[4 * (i - fw)], lum[4 * (i - 1)], lum[4 * i], lum[4 * (i + 1)], lum[4 * (i + fw)]);
   }
   __syncthreads();
 }
 
 struct rgbf_t { float r, g, b; };
 
-// FsrEasuF for one output pixel whose 'f' texel sits at footprint index f_idx and whose sub-texel
-// position is (ppx, ppy) (:324-326 done by the caller).  Returns aC * rcp(aW) (:437 before the
-// dering clamp).  Everything up to the `dirR < 1/32768` decision is evaluated in the reference's exact
-// operation order: that decision (and floor() in the caller) are the filter's only discontinuities.
-template <bool EXACT>
-__device__ __forceinline__ rgbf_t easu_pixel(const EasuLds& l, int f_idx, float ppx, float ppy) {
-  const int fw = l.fw;
+// The FsrEasuF filter for one output pixel (ffx_fsr1.h:381-437 without the dering clamp): sub-texel position (ppx, ppy)
+// (:324-326 done by the caller), the 12-tap window through `tex(dx, dy)` -> (R, G, B, .) with (0, 0) the texel 'f', and
+// the four analyses through `ana(k)`, k = 0..3 for f, g, j, k (easu_analysis).  Returns aC * rcp(aW).  Everything up to
+// the `dirR < 1/32768` decision is evaluated in the reference's exact operation order: that decision (and floor() in
+// the caller) are the filter's only discontinuities.
+template <bool EXACT, class Tex, class Ana>
+__device__ __forceinline__ rgbf_t easu_filter(const Tex& tex, const Ana& ana, float ppx, float ppy) {
   const float omx = 1.0f - ppx, omy = 1.0f - ppy;
   // :381-386 bilinear accumulation of the 4 analyses (f,g,j,k), reference order:
   //   dir.x += dirX*w ; len += lenX*w ; dir.y += dirY*w ; len += lenY*w   for s,t,u,v in turn.
-  const float4_t af = l.ana[f_idx], ag = l.ana[f_idx + 1], aj = l.ana[f_idx + fw], ak = l.ana[f_idx + fw + 1];
+  const float4_t af = ana(0), ag = ana(1), aj = ana(2), ak = ana(3);
   const float wS = omx * omy, wT = ppx * omy, wU = omx * ppy, wV = ppx * ppy;
   float dirx = af.x * wS;  // 0 + x is exact, so the first add of each chain is dropped
   float diry = af.y * wS;
@@ -154,7 +161,7 @@ __device__ __forceinline__ rgbf_t easu_pixel(const EasuLds& l, int f_idx, float 
   const float oym = -1.0f - ppy, oy0 = 0.0f - ppy, oy1 = 1.0f - ppy, oy2 = 2.0f - ppy;
   if (EXACT) {
     auto tap = [&](int dx, int dy, float offx, float offy) {
-      const float4_t c = l.tex[f_idx + dy * fw + dx];
+      const float4_t c = tex(dx, dy);
       float vx = (offx * dirx) + (offy * diry);
       float vy = (offx * (-diry)) + (offy * dirx);
       vx *= len2x;
@@ -194,13 +201,13 @@ __device__ __forceinline__ rgbf_t easu_pixel(const EasuLds& l, int f_idx, float 
       return base * (wa * wa);
     };
     auto tap = [&](int dx, int dy, float ox, float s, float b) {
-      const float4_t c = l.tex[f_idx + dy * fw + dx];
+      const float4_t c = tex(dx, dy);
       const float w = weight(ox, s, b);
       aR = fmaf(c.x, w, aR); aG = fmaf(c.y, w, aG); aB = fmaf(c.z, w, aB);
       aW += w;
     };
     {  // the first tap starts the sums
-      const float4_t c = l.tex[f_idx - fw];
+      const float4_t c = tex(0, -1);
       aW = weight(ox0, sm, bm);
       aR = c.x * aW; aG = c.y * aW; aB = c.z * aW;
     }
@@ -214,6 +221,14 @@ __device__ __forceinline__ rgbf_t easu_pixel(const EasuLds& l, int f_idx, float 
   // pinned in every variant: the narrowing that follows must round the binary32 product, not re-fuse it
   // (v_fma_mixlo_f16), or two kernels sharing this code could round the same pixel differently
   return rgbf_t{pinned(aR * rW), pinned(aG * rW), pinned(aB * rW)};
+}
+
+// The filter on a staged footprint: 'f' sits at footprint index f_idx.
+template <bool EXACT>
+__device__ __forceinline__ rgbf_t easu_pixel(const EasuLds& l, int f_idx, float ppx, float ppy) {
+  const int fw = l.fw;
+  return easu_filter<EXACT>([&](int dx, int dy) { return l.tex[f_idx + dy * fw + dx]; },
+                            [&](int k) { return l.ana[f_idx + (k >> 1) * fw + (k & 1)]; }, ppx, ppy);
 }
 
 // Dering bounds (:416-419): per-channel min and max of the 2x2 block f g / j k whose top-left texel is f_idx.
@@ -233,11 +248,14 @@ __device__ __forceinline__ float max4_asm(float a, float b, float c, float d) {
   return t;
 }
 
-__device__ __forceinline__ EasuBounds easu_bounds(const EasuLds& l, int f_idx) {
-  const int fw = l.fw;
-  const float4_t cf = l.tex[f_idx], cg = l.tex[f_idx + 1], cj = l.tex[f_idx + fw], ck = l.tex[f_idx + fw + 1];
+__device__ __forceinline__ EasuBounds easu_bounds(float4_t cf, float4_t cg, float4_t cj, float4_t ck) {
   return EasuBounds{min4_asm(cf.x, cg.x, cj.x, ck.x), min4_asm(cf.y, cg.y, cj.y, ck.y), min4_asm(cf.z, cg.z, cj.z, ck.z),
                     max4_asm(cf.x, cg.x, cj.x, ck.x), max4_asm(cf.y, cg.y, cj.y, ck.y), max4_asm(cf.z, cg.z, cj.z, ck.z)};
+}
+
+__device__ __forceinline__ EasuBounds easu_bounds(const EasuLds& l, int f_idx) {
+  const int fw = l.fw;
+  return easu_bounds(l.tex[f_idx], l.tex[f_idx + 1], l.tex[f_idx + fw], l.tex[f_idx + fw + 1]);
 }
 
 // Dering clamp in binary32 (:437 `min(max4, max(min4, pix))`) + optional `c *= c` (FSR_Pass.hlsl:78-79): the filter's

@@ -1,0 +1,199 @@
+// Packed-binary16 (parity class "H") building blocks of the FSR 1.0 HIP operator surface: FsrEasuH
+// (ffx-fsr/ffx_fsr1.h:445-593) and FsrRcasH / FsrRcasHx2 (:777-984) as native _Float16 vector arithmetic.
+//
+// Every arithmetic operation of the reference's half-precision path is ONE native binary16 operation here, in the
+// reference's order, with contraction off (-ffp-contract=off), so the results are bit-identical to the reference's H
+// path evaluated with round-to-nearest-even after every operation.  ARcpH (GLSL `1.0/x`) is half_rcp() of
+// fsr1_device_base.hpp: the correctly rounded quotient.
+#pragma once
+#include "fsr1_device_base.hpp"
+
+namespace fsr1 {
+
+typedef unsigned short u16;
+
+__device__ __forceinline__ half2_t h2(half_t a, half_t b) { return half2_t{a, b}; }
+__device__ __forceinline__ half2_t h2s(half_t a) { return half2_t{a, a}; }
+__device__ __forceinline__ half2_t habs2(half2_t a) { return __builtin_elementwise_abs(a); }
+__device__ __forceinline__ half2_t hmax2(half2_t a, half2_t b) { return __builtin_elementwise_max(a, b); }  // v_pk_max_f16 (maxNum)
+__device__ __forceinline__ half2_t hmin2(half2_t a, half2_t b) { return __builtin_elementwise_min(a, b); }
+__device__ __forceinline__ half_t hmax1(half_t a, half_t b) { return __builtin_fmaxf16(a, b); }
+__device__ __forceinline__ half_t hmin1(half_t a, half_t b) { return __builtin_fminf16(a, b); }
+__device__ __forceinline__ half_t habs1(half_t a) { return __builtin_fabsf16(a); }
+// ASatH2, ffx_a.h:896 — clamp(x, 0, 1)
+__device__ __forceinline__ half2_t hsat2(half2_t a) { return hmin2(hmax2(a, h2s((half_t)0.0f)), h2s((half_t)1.0f)); }
+// ARcpH1/ARcpH2 (GLSL: 1.0/x): correctly rounded binary16 quotient
+__device__ __forceinline__ half_t hrcp1(half_t a) { return half_rcp(a); }
+__device__ __forceinline__ half2_t hrcp2(half2_t a) { return half2_t{hrcp1(a.x), hrcp1(a.y)}; }
+// ffx_a.h:1808, :1820 — integer tricks on the binary16 pattern (16-bit wrap-around subtraction)
+__device__ __forceinline__ half_t APrxLoRcpH1(half_t a) { return __builtin_bit_cast(half_t, (u16)(0x7784u - __builtin_bit_cast(u16, a))); }
+__device__ __forceinline__ half_t APrxLoRsqH1(half_t a) { return __builtin_bit_cast(half_t, (u16)(0x59a3u - (__builtin_bit_cast(u16, a) >> 1))); }
+
+// as / from the bit pattern of a pair; swap the two halves
+__device__ __forceinline__ half2_t as_h2(uint32_t u) { return __builtin_bit_cast(half2_t, u); }
+__device__ __forceinline__ uint32_t as_u(half2_t h) { return __builtin_bit_cast(uint32_t, h); }
+__device__ __forceinline__ half2_t swap2(half2_t a) { return __builtin_shufflevector(a, a, 1, 0); }
+
+// FsrEasuSetH's terms for ONE position (one AH2 lane of :486-502) of the '+' neighbourhood  a / b c d / e , before the
+// bilinear weighting: (dirX, dirY, lenX^2, lenY^2).  They depend on the input image only, so the tiled kernel evaluates
+// them once per input texel; the per-pixel accumulation then sees operands bit-identical to the reference's.
+__device__ __forceinline__ half4_t easu_analysis_h(half_t lA, half_t lB, half_t lC, half_t lD, half_t lE) {
+  const half_t one = (half_t)1.0f, zero = (half_t)0.0f;
+  const half_t dc = lD - lC, cb = lC - lB;
+  half_t lenX = hrcp1(hmax1(habs1(dc), habs1(cb)));
+  const half_t dirX = lD - lB;
+  lenX = hmin1(hmax1(habs1(dirX) * lenX, zero), one);
+  lenX = lenX * lenX;
+  const half_t ec = lE - lC, ca = lC - lA;
+  half_t lenY = hrcp1(hmax1(habs1(ec), habs1(ca)));
+  const half_t dirY = lE - lA;
+  lenY = hmin1(hmax1(habs1(dirY) * lenY, zero), one);
+  lenY = lenY * lenY;
+  return half4_t{dirX, dirY, lenX, lenY};
+}
+
+// :575-577 min and max of a channel over the 2x2 block f g / j k through max() of (-x, x) pairs: (.x = -min, .y = max)
+__device__ __forceinline__ half2_t easu_both_h(half_t f, half_t g, half_t j, half_t k) {
+  return hmax2(hmax2(h2(-f, f), h2(-g, g)), hmax2(h2(-j, j), h2(-k, k)));
+}
+
+struct EasuHTaps { half2_t pR, pG, pB, pW; };
+
+// FsrEasuTapH :452-473 — two taps per call
+__device__ __forceinline__ void easu_tap_h(EasuHTaps& p, half2_t offX, half2_t offY, half2_t dir, half2_t len, half_t lob, half_t clp,
+                                           half2_t cR, half2_t cG, half2_t cB) {
+  half2_t vX = offX * h2s(dir.x) + offY * h2s(dir.y);
+  half2_t vY = offX * h2s(-dir.y) + offY * h2s(dir.x);
+  vX = vX * h2s(len.x);
+  vY = vY * h2s(len.y);
+  half2_t d2 = vX * vX + vY * vY;
+  d2 = hmin2(d2, h2s(clp));
+  half2_t wB = h2s((half_t)(2.0 / 5.0)) * d2 + h2s((half_t)-1.0f);
+  half2_t wA = h2s(lob) * d2 + h2s((half_t)-1.0f);
+  wB = wB * wB;
+  wA = wA * wA;
+  wB = h2s((half_t)(25.0 / 16.0)) * wB + h2s((half_t)(-(25.0 / 16.0 - 1.0)));
+  const half2_t w = wB * wA;
+  p.pR = p.pR + cR * w;
+  p.pG = p.pG + cG * w;
+  p.pB = p.pB + cB * w;
+  p.pW = p.pW + w;
+}
+
+// FsrEasuH from the point where the taps are known (:552-593).  ppp = AH2(pp) (:516).
+//   ana(k)   k = 0..3 for f, g, j, k -> easu_analysis_h of that texel
+//   pair(i)  i = 0..5 -> the (cR, cG, cB) operands of the reference's six FsrEasuTapH calls, in its order:
+//            (b,c) (i,j) (f,e) (k,l) (h,g) (o,n)      (:579-588)
+//   both(c)  c = 0..2 -> easu_both_h of channel R, G, B
+struct EasuHPair { half2_t r, g, b; };
+struct rgbh_t { half_t r, g, b; };
+template <class Ana, class PairFn, class Both>
+__device__ __forceinline__ rgbh_t easu_filter_h(const Ana& ana, const PairFn& pair, const Both& both, half2_t ppp) {
+  const half_t one = (half_t)1.0f, zero = (half_t)0.0f;
+  // :552-558 the two FsrEasuSetH calls: lanes (f, g) with weights w1, lanes (j, k) with weights w2
+  const half2_t wx = h2(one, zero) + h2(-ppp.x, ppp.x);  // :483-484
+  const half2_t w1 = wx * h2s(one - ppp.y), w2 = wx * h2s(ppp.y);
+  const half4_t af = ana(0), ag = ana(1), aj = ana(2), ak = ana(3);
+  half2_t dirPX = h2s(zero), dirPY = h2s(zero), lenP = h2s(zero);
+  dirPX = dirPX + h2(af.x, ag.x) * w1;
+  lenP = lenP + h2(af.z, ag.z) * w1;
+  dirPY = dirPY + h2(af.y, ag.y) * w1;
+  lenP = lenP + h2(af.w, ag.w) * w1;
+  dirPX = dirPX + h2(aj.x, ak.x) * w2;
+  lenP = lenP + h2(aj.z, ak.z) * w2;
+  dirPY = dirPY + h2(aj.y, ak.y) * w2;
+  lenP = lenP + h2(aj.w, ak.w) * w2;
+  half2_t dir = h2(dirPX.x + dirPX.y, dirPY.x + dirPY.y);
+  half_t len = lenP.x + lenP.y;
+  // :560-572
+  const half2_t dir2 = dir * dir;
+  half_t dirR = dir2.x + dir2.y;
+  const bool zro = dirR < (half_t)(1.0 / 32768.0);
+  dirR = APrxLoRsqH1(dirR);
+  dirR = zro ? one : dirR;
+  dir.x = zro ? one : dir.x;
+  dir = dir * h2s(dirR);
+  len = len * (half_t)0.5f;
+  len = len * len;
+  const half_t stretch = (dir.x * dir.x + dir.y * dir.y) * APrxLoRcpH1(hmax1(habs1(dir.x), habs1(dir.y)));
+  const half2_t len2 = h2(one + (stretch - one) * len, one + (half_t)-0.5f * len);
+  const half_t lob = (half_t)0.5f + (half_t)((1.0 / 4.0 - 0.04) - 0.5) * len;
+  const half_t clp = APrxLoRcpH1(lob);
+  // :579-588
+  EasuHTaps p = {h2s(zero), h2s(zero), h2s(zero), h2s(zero)};
+  const half2_t px2 = h2s(ppp.x), py2 = h2s(ppp.y);
+  const half_t two = (half_t)2.0f;
+  const EasuHPair bc = pair(0), ij = pair(1), fe = pair(2), kl = pair(3), hg = pair(4), on = pair(5);
+  easu_tap_h(p, h2(zero, one) - px2, h2(-one, -one) - py2, dir, len2, lob, clp, bc.r, bc.g, bc.b);
+  easu_tap_h(p, h2(-one, zero) - px2, h2(one, one) - py2, dir, len2, lob, clp, ij.r, ij.g, ij.b);
+  easu_tap_h(p, h2(zero, -one) - px2, h2(zero, zero) - py2, dir, len2, lob, clp, fe.r, fe.g, fe.b);
+  easu_tap_h(p, h2(one, two) - px2, h2(one, one) - py2, dir, len2, lob, clp, kl.r, kl.g, kl.b);
+  easu_tap_h(p, h2(two, one) - px2, h2(zero, zero) - py2, dir, len2, lob, clp, hg.r, hg.g, hg.b);
+  easu_tap_h(p, h2(one, zero) - px2, h2(two, two) - py2, dir, len2, lob, clp, on.r, on.g, on.b);
+  const half_t aR = p.pR.x + p.pR.y, aG = p.pG.x + p.pG.y, aB = p.pB.x + p.pB.y;
+  const half_t aW = p.pW.x + p.pW.y;
+  // :593
+  const half2_t bothR = both(0), bothG = both(1), bothB = both(2);
+  const half_t rW = hrcp1(aW);
+  return rgbh_t{hmin1(bothR.y, hmax1(-bothR.x, aR * rW)), hmin1(bothG.y, hmax1(-bothG.x, aG * rW)), hmin1(bothB.y, hmax1(-bothB.x, aB * rW))};
+}
+
+// ---- RCAS, two pixels per call in the two halves of every operand (FsrRcasHx2's arithmetic, :913-984) ----
+struct soa_t { half2_t r, g, b, a; };  // two pixels: .x = left (even column), .y = right
+
+__device__ __forceinline__ half2_t mx2(half2_t a, half2_t b) { return __builtin_elementwise_max(a, b); }
+__device__ __forceinline__ half2_t mn2(half2_t a, half2_t b) { return __builtin_elementwise_min(a, b); }
+__device__ __forceinline__ half2_t ab2(half2_t a) { return __builtin_elementwise_abs(a); }
+__device__ __forceinline__ half2_t s2(float v) { return half2_t{(half_t)v, (half_t)v}; }
+__device__ __forceinline__ half2_t rcp2(half2_t a) { return half2_t{half_rcp(a.x), half_rcp(a.y)}; }  // ARcpH2: correctly rounded
+// AMin3H2(x,y,z) = min(x, min(y, z)), ffx_a.h:1150 ; AMax3H2 likewise
+__device__ __forceinline__ half2_t mn3(half2_t x, half2_t y, half2_t z) { return mn2(x, mn2(y, z)); }
+__device__ __forceinline__ half2_t mx3(half2_t x, half2_t y, half2_t z) { return mx2(x, mx2(y, z)); }
+// APrxMedRcpH2, ffx_a.h:1816: b = bits(0x778d - bits(a)); b*(-b*a + 2)
+__device__ __forceinline__ half2_t prx_med_rcp2(half2_t a) {
+  typedef u16 u16x2 __attribute__((ext_vector_type(2)));
+  const u16x2 k = {0x778du, 0x778du};
+  const half2_t b = __builtin_bit_cast(half2_t, (u16x2)(k - __builtin_bit_cast(u16x2, a)));
+  return b * (-b * a + s2(2.0f));
+}
+
+// One FsrRcasHx2 evaluation from its taps (b above, d left, e centre, f right, h below; each a pair of pixels per
+// channel).  `sharp1` = AH2_AU1(con.y).x, the packed half of con[1] (:857).  Returns the pair of sharpened pixels
+// (alpha is the caller's: 1 or the centre tap's, :905-907).
+struct rgbh2_t { half2_t r, g, b; };
+__device__ __forceinline__ rgbh2_t rcas_pixel_h2(half2_t bR, half2_t bG, half2_t bB, half2_t dR, half2_t dG, half2_t dB, half2_t eR, half2_t eG,
+                                                 half2_t eB, half2_t fR, half2_t fG, half2_t fB, half2_t hR, half2_t hG, half2_t hB, half_t sharp1,
+                                                 uint32_t flags) {
+  const half2_t sharp = {sharp1, sharp1};
+  const half2_t hlf = s2(0.5f), qtr = s2(0.25f), four = s2(4.0f), one = s2(1.0f);
+  // :946-951 min and max of ring
+  const half2_t mn4R = mn2(mn3(bR, dR, fR), hR), mn4G = mn2(mn3(bG, dG, fG), hG), mn4B = mn2(mn3(bB, dB, fB), hB);
+  const half2_t mx4R = mx2(mx3(bR, dR, fR), hR), mx4G = mx2(mx3(bG, dG, fG), hG), mx4B = mx2(mx3(bB, dB, fB), hB);
+  // :953-961 limiters (peakC = (1, -4))
+  const half2_t m4 = s2(-4.0f);
+  const half2_t hitMinR = mn2(mn4R, eR) * rcp2(four * mx4R);
+  const half2_t hitMinG = mn2(mn4G, eG) * rcp2(four * mx4G);
+  const half2_t hitMinB = mn2(mn4B, eB) * rcp2(four * mx4B);
+  const half2_t hitMaxR = (one - mx2(mx4R, eR)) * rcp2(four * mn4R + m4);
+  const half2_t hitMaxG = (one - mx2(mx4G, eG)) * rcp2(four * mn4G + m4);
+  const half2_t hitMaxB = (one - mx2(mx4B, eB)) * rcp2(four * mn4B + m4);
+  const half2_t lobeR = mx2(-hitMinR, hitMaxR), lobeG = mx2(-hitMinG, hitMaxG), lobeB = mx2(-hitMinB, hitMaxB);
+  half2_t lobe = mx2(s2(-(0.25f - (1.0f / 16.0f))), mn2(mx3(lobeR, lobeG, lobeB), s2(0.0f))) * sharp;
+  if (flags & FSR1_FLAG_RCAS_DENOISE) {  // :935-944, :969-971
+    const half2_t bL = bB * hlf + (bR * hlf + bG), dL = dB * hlf + (dR * hlf + dG), eL = eB * hlf + (eR * hlf + eG);
+    const half2_t fL = fB * hlf + (fR * hlf + fG), hL = hB * hlf + (hR * hlf + hG);
+    half2_t nz = qtr * bL + qtr * dL + qtr * fL + qtr * hL - eL;
+    nz = mn2(mx2(ab2(nz) * prx_med_rcp2(mx3(mx3(bL, dL, eL), fL, hL) - mn3(mn3(bL, dL, eL), fL, hL)), s2(0.0f)), one);
+    nz = s2(-0.5f) * nz + one;
+    lobe = lobe * nz;
+  }
+  // :973-976 resolve
+  const half2_t rcpL = prx_med_rcp2(four * lobe + one);
+  half2_t pR = (lobe * bR + lobe * dR + lobe * hR + lobe * fR + eR) * rcpL;
+  half2_t pG = (lobe * bG + lobe * dG + lobe * hG + lobe * fG + eG) * rcpL;
+  half2_t pB = (lobe * bB + lobe * dB + lobe * hB + lobe * fB + eB) * rcpL;
+  if (flags & FSR1_FLAG_HDR_SQUARE) { pR = pR * pR; pG = pG * pG; pB = pB * pB; }  // FSR_Pass.hlsl:92-93
+  return rgbh2_t{pR, pG, pB};
+}
+
+}  // namespace fsr1

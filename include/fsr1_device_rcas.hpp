@@ -1,7 +1,7 @@
 // FsrRcasF per-pixel arithmetic (ffx-fsr/ffx_fsr1.h:684-769), shared by the RCAS kernel and the fused
 // EASU->RCAS kernel.
 #pragma once
-#include "fsr1_device.h"
+#include "fsr1_device_base.hpp"
 
 namespace fsr1 {
 

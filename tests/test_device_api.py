@@ -1,0 +1,182 @@
+"""The device-side, source-level operator surface (include/fsr1_device.hpp): FsrEasuF / FsrEasuH / FsrRcasF / FsrRcasH
+called from an OUTSIDE kernel — tests/device_api/outside_kernel.hip, an "integrator's" translation unit compiled
+against include/ only — with caller-supplied load callbacks, the reference's plugin shape
+(ffx_fsr1.h:232-236, :315-322, :505-512, :679-690, :777-790; includer side sample/src/DX12/FSR_Pass.hlsl:28-66).
+
+CPU part: the outside kernel compiles for gfx950 with nothing but include/ on its include path, and exports its entry
+points.  GPU part (-m gpu): its results equal the golden vectors (generated from the reference headers compiled
+verbatim) bit for bit — EXACT arithmetic for the F entry points, always for the H ones — and the LDS-staged fast
+form used from outside equals them too.
+"""
+import ctypes
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import PIXEL_CASES, ROOT, load_golden
+
+HERE = os.path.join(ROOT, "tests", "device_api")
+LIB = os.path.join(HERE, "liboutside_kernel.so")
+ENTRY_POINTS = ["outside_easu_f", "outside_rcas_f", "outside_easu_h", "outside_rcas_h", "outside_easu_tiled"]
+
+
+def build_outside():
+    subprocess.check_call(["make", "-C", HERE], stdout=subprocess.DEVNULL)
+    return LIB
+
+
+def test_outside_kernel_sees_include_only():
+    """The integrator's compile line has include/ on its path and nothing of the library's csrc/."""
+    mk = open(os.path.join(HERE, "Makefile")).read()
+    incs = re.findall(r"-I(\S+)", mk)
+    assert incs == ["../../include"], incs
+    src = open(os.path.join(HERE, "outside_kernel.hip")).read()
+    for inc in re.findall(r'#include\s+"([^"]+)"', src):
+        assert os.path.exists(os.path.join(ROOT, "include", inc)), inc + " is not a public header"
+    # and the public headers include only each other (plus system headers)
+    for name in os.listdir(os.path.join(ROOT, "include")):
+        for inc in re.findall(r'#include\s+"([^"]+)"', open(os.path.join(ROOT, "include", name)).read()):
+            assert os.path.exists(os.path.join(ROOT, "include", inc)), "%s includes non-public %s" % (name, inc)
+
+
+def test_outside_kernel_compiles_against_include_only():
+    lib = build_outside()
+    out = subprocess.check_output(["nm", "-D", "--defined-only", lib], text=True)
+    for sym in ENTRY_POINTS:
+        assert re.search(r"\bT %s\b" % sym, out), sym + " not exported"
+
+
+def test_library_kernels_use_the_public_headers():
+    """The product's own kernels are built from the very headers an integrator gets (no private copy of the arithmetic)."""
+    csrc = os.path.join(ROOT, "fidelityfx-fsr_amd", "csrc")
+    text = "".join(open(os.path.join(csrc, f)).read() for f in os.listdir(csrc) if f.endswith((".hip", ".h")))
+    for hdr in ("fsr1_device_base.hpp", "fsr1_device_easu.hpp", "fsr1_device_rcas.hpp", "fsr1_device_half.hpp", "fsr1_device_color.hpp"):
+        assert '#include "%s"' % hdr in text, hdr
+    for gone in ("fsr1_easu_math.h", "fsr1_rcas_math.h", "fsr1_color_math.h"):
+        assert not os.path.exists(os.path.join(csrc, gone))
+
+
+# ------------------------------------------------------------------------------------------------------------------
+gpu = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def outside():
+    torch = pytest.importorskip("torch")
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    lib = ctypes.CDLL(build_outside())
+    vp, ip, up, fl = ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_uint32), ctypes.c_float
+    lib.outside_easu_f.argtypes = [vp, ip, ip, vp, ip, ip, up, ip, ip]
+    lib.outside_rcas_f.argtypes = [vp, ip, ip, vp, up, ip, ip, fl]
+    lib.outside_easu_h.argtypes = [vp, ip, ip, vp, ip, ip, up]
+    lib.outside_rcas_h.argtypes = [vp, ip, ip, vp, up, ip]
+    lib.outside_easu_tiled.argtypes = [vp, ip, ip, vp, ip, ip, up, ip]
+    return lib
+
+
+def _u32(a):
+    a = np.ascontiguousarray(a, np.uint32)
+    return a, a.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32))
+
+
+def _dev(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _bits32(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def _same32(got, want, what):
+    bad = (_bits32(got) != _bits32(want)) & ~(np.isnan(got) & np.isnan(want))
+    assert not bad.any(), "%s: %d of %d binary32 values differ (first at %s)" % (what, bad.sum(), bad.size, np.argwhere(bad)[:3].tolist())
+
+
+def _same16(got, want, what):
+    g = np.ascontiguousarray(got).astype(np.float16).view(np.uint16)
+    o = np.ascontiguousarray(want).astype(np.float16).view(np.uint16)
+    nan = np.isnan(np.asarray(got, np.float32)) & np.isnan(np.asarray(want, np.float32))
+    bad = (g != o) & ~nan
+    assert not bad.any(), "%s: %d of %d binary16 values differ (first at %s)" % (what, bad.sum(), bad.size, np.argwhere(bad)[:3].tolist())
+
+
+@gpu
+@pytest.mark.parametrize("name", PIXEL_CASES)
+def test_outside_easu_f_matches_goldens(outside, name):
+    import torch
+    g = load_golden(name)
+    ih, iw = g["input"].shape[:2]
+    oh, ow = g["easu_f"].shape[:2]
+    src = _dev(g["input"].astype(np.float32))
+    out = torch.zeros(oh, ow, 4, dtype=torch.float32, device="cuda")
+    con, conp = _u32(g["con"])
+    assert outside.outside_easu_f(src.data_ptr(), iw, ih, out.data_ptr(), ow, oh, conp, 1, 0) == 0
+    _same32(out.cpu().numpy(), g["easu_f"], name + " FsrEasuF EXACT from an outside kernel")
+    assert outside.outside_easu_f(src.data_ptr(), iw, ih, out.data_ptr(), ow, oh, conp, 1, 1) == 0
+    _same32(out.cpu().numpy(), g["easu_f_hdr"], name + " FsrEasuF EXACT + hdr square")
+    # default arithmetic: within 1 binary16 ULP of the reference
+    import cpu_oracle
+    assert outside.outside_easu_f(src.data_ptr(), iw, ih, out.data_ptr(), ow, oh, conp, 0, 0) == 0
+    assert cpu_oracle.half_ulp_diff(out.cpu().numpy(), g["easu_f"]).max() <= 1
+    # the LDS-staged fast form, used from outside
+    out.zero_()
+    assert outside.outside_easu_tiled(src.data_ptr(), iw, ih, out.data_ptr(), ow, oh, conp, 1) == 0
+    _same32(out.cpu().numpy(), g["easu_f"], name + " tiled form EXACT from an outside kernel")
+    out.zero_()
+    assert outside.outside_easu_tiled(src.data_ptr(), iw, ih, out.data_ptr(), ow, oh, conp, 0) == 0
+    assert cpu_oracle.half_ulp_diff(out.cpu().numpy(), g["easu_f"]).max() <= 1
+
+
+@gpu
+@pytest.mark.parametrize("name", PIXEL_CASES)
+def test_outside_rcas_f_matches_goldens(outside, name):
+    import torch
+    g = load_golden(name)
+    mid = g["mid"].astype(np.float32)
+    h, w = mid.shape[:2]
+    src = _dev(mid)
+    out = torch.zeros(h, w, 4, dtype=torch.float32, device="cuda")
+    con, conp = _u32(g["rcas_con"])
+    for variant in (0, 1, 2, 3):  # bit 0 FSR_RCAS_DENOISE, bit 1 FSR_RCAS_PASSTHROUGH_ALPHA: the goldens' rcas_f_N
+        assert outside.outside_rcas_f(src.data_ptr(), w, h, out.data_ptr(), conp, 1, variant, 1.0) == 0
+        _same32(out.cpu().numpy(), g["rcas_f_%d" % variant], "%s FsrRcasF EXACT variant %d" % (name, variant))
+
+
+@gpu
+def test_outside_rcas_input_callback_is_applied(outside, port):
+    """The FsrRcasInputF hook (ffx_fsr1.h:682, :725-729): scaling every tap by s equals running the filter on s * image."""
+    import torch
+    g = load_golden("perf_2p0x")
+    mid = g["mid"].astype(np.float32)
+    h, w = mid.shape[:2]
+    out = torch.zeros(h, w, 4, dtype=torch.float32, device="cuda")
+    con, conp = _u32(g["rcas_con"])
+    assert outside.outside_rcas_f(_dev(mid).data_ptr(), w, h, out.data_ptr(), conp, 1, 0, 0.5) == 0
+    scaled = mid.copy()
+    scaled[..., :3] *= np.float32(0.5)
+    _same32(out.cpu().numpy(), port.rcas_f(scaled, con), "FsrRcasInputF scale 0.5")
+
+
+@gpu
+@pytest.mark.parametrize("name", PIXEL_CASES)
+def test_outside_h_entry_points_match_goldens(outside, name):
+    import torch
+    g = load_golden(name)
+    ih, iw = g["input"].shape[:2]
+    oh, ow = g["easu_h"].shape[:2]
+    src = _dev(g["input"].astype(np.float16))
+    out = torch.zeros(oh, ow, 4, dtype=torch.float16, device="cuda")
+    con, conp = _u32(g["con"])
+    assert outside.outside_easu_h(src.data_ptr(), iw, ih, out.data_ptr(), ow, oh, conp) == 0
+    _same16(out.cpu().numpy(), g["easu_h"], name + " FsrEasuH from an outside kernel")
+    mid = _dev(g["mid"].astype(np.float16))
+    rcon, rconp = _u32(g["rcas_con"])
+    for variant in (0, 1, 2, 3):
+        o2 = torch.zeros_like(mid)
+        assert outside.outside_rcas_h(mid.data_ptr(), ow, oh, o2.data_ptr(), rconp, variant) == 0
+        _same16(o2.cpu().numpy(), g["rcas_h_%d" % variant], "%s FsrRcasH variant %d" % (name, variant))
