@@ -4,15 +4,17 @@
  * SampleRenderer::OnRender, SampleRenderer.cpp:705-709) without the renderer around it.
  *
  * One process, one host thread per GPU.  Frames are independent (FSR 1.0 keeps no history), so a
- * batch of F frames is sharded in contiguous blocks over the GPUs; every thread uploads its frames once,
- * then runs K timed steps of  FsrEasuCon -> EASU -> FsrRcasCon -> RCAS  over its block through the C ABI of
- * libfsr1_hip.so, timing with HIP events on its own stream.  The only inter-GPU traffic is one RCCL
+ * batch of F frames is sharded in contiguous blocks over the GPUs; every thread uploads its frames once
+ * into a RING of frame sets (input, intermediary, output) larger than the 256 MiB Infinity Cache — so that, like a video
+ * stream and like bench.py, every step reads its input from HBM rather than from a cache-resident copy — then runs K
+ * timed steps of  FsrEasuCon -> EASU -> FsrRcasCon -> RCAS  over its block through the C ABI of libfsr1_hip.so, step i
+ * on set i % ring, timing with HIP events on its own stream.  The only inter-GPU traffic is one RCCL
  * all-gather of the per-GPU throughput counters {frames, output pixels, device ns} over xGMI; no image
  * data ever crosses a link.  Rank 0 prints one JSON line.
  *
  *   fsr1_runner [--gpus N] [--frames F] [--in WxH] [--out WxH] [--steps K] [--warmup W]
- *               [--pipeline two-pass|fused|easu|auto] [--math f|exact] [--sharpness STOPS] [--hdr]
- *               [--stages BITS] [--grain AMOUNT]
+ *               [--pipeline two-pass|fused|easu|auto] [--math f|exact|h] [--sharpness STOPS] [--hdr]
+ *               [--stages BITS] [--grain AMOUNT] [--ring R]
  *
  * --stages fuses colour stages into the passes (FSR1_COLOR_* bits of fsr1_hip.h: 1 FsrSrtmF on the input, 2 FsrLfgaF
  * film grain, 4 FsrSrtmInvF, 8 / 16 FsrTepdC8F / FsrTepdC10F dither) — what the sample's colour pass does around the
@@ -22,6 +24,7 @@
 #include <hip/hip_runtime_api.h>
 #include <math.h>
 #include <pthread.h>
+#include <stdatomic.h>
 #include <rccl/rccl.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -37,7 +40,13 @@ typedef struct {
   float sharpness;
   uint32_t stages; /* FSR1_COLOR_* */
   float grain;
+  int ring; /* frame sets to rotate over; 0 = enough to exceed the 256 MiB Infinity Cache */
 } options_t;
+
+/* A rank that fails must not leave the others blocked in the collective: every rank reaches this barrier, failed or
+ * not, and the all-gather runs only if no rank raised the flag. */
+static atomic_int g_abort;
+static pthread_barrier_t g_before_collective;
 
 typedef struct {
   const options_t* opt;
@@ -48,6 +57,12 @@ typedef struct {
   uint64_t* gathered;    /* rank 0: [gpus][3] */
   int status;
   char error[256];
+  int ring;
+  /* device resources, released by worker() after the collective */
+  hipStream_t stream;
+  hipEvent_t ev0, ev1;
+  void *d_in, *d_mid, *d_out, *d_noise;
+  uint64_t *d_send, *d_recv;
 } worker_t;
 
 #define HIP_OK(w, call)                                                                          \
@@ -56,7 +71,7 @@ typedef struct {
     if (e_ != hipSuccess) {                                                                      \
       snprintf((w)->error, sizeof (w)->error, "%s: %s", #call, hipGetErrorString(e_));           \
       (w)->status = -1;                                                                          \
-      return NULL;                                                                               \
+      return -1;                                                                                 \
     }                                                                                            \
   } while (0)
 #define FSR_OK(w, call)                                                                          \
@@ -65,7 +80,7 @@ typedef struct {
     if (rc_ != 0) {                                                                              \
       snprintf((w)->error, sizeof (w)->error, "%s: %s", #call, fsr1_last_error());               \
       (w)->status = rc_;                                                                         \
-      return NULL;                                                                               \
+      return -1;                                                                                 \
     }                                                                                            \
   } while (0)
 #define NCCL_OK(w, call)                                                                         \
@@ -74,7 +89,7 @@ typedef struct {
     if (r_ != ncclSuccess) {                                                                     \
       snprintf((w)->error, sizeof (w)->error, "%s: %s", #call, ncclGetErrorString(r_));          \
       (w)->status = -2;                                                                          \
-      return NULL;                                                                               \
+      return -1;                                                                                 \
     }                                                                                            \
   } while (0)
 
@@ -126,51 +141,56 @@ static void shard(int total, int rank, int world, int* begin, int* end) {
   *end = *begin + q + (rank < r ? 1 : 0);
 }
 
-static void* worker(void* arg) {
-  worker_t* w = (worker_t*)arg;
+static int worker_body(worker_t* w) {
   const options_t* o = w->opt;
   int f0, f1;
   shard(o->frames, w->rank, o->gpus, &f0, &f1);
   const int nf = f1 - f0;
   HIP_OK(w, hipSetDevice(w->rank));
-  hipStream_t stream;
-  HIP_OK(w, hipStreamCreate(&stream));
+  HIP_OK(w, hipStreamCreate(&w->stream));
+  hipStream_t stream = w->stream;
 
+  const int needs_mid = o->pipeline == 0 || o->pipeline == 3;
   const size_t in_frame = (size_t)o->in_w * o->in_h * 8, out_frame = (size_t)o->out_w * o->out_h * 8;
-  void *d_in = NULL, *d_mid = NULL, *d_out = NULL;
+  const size_t set_bytes = (in_frame + out_frame * (needs_mid ? 2 : 1)) * (size_t)(nf > 0 ? nf : 1);
+  int ring = o->ring;
+  if (ring <= 0) {
+    ring = (int)((320u * 1024u * 1024u + set_bytes - 1) / set_bytes);
+    if (ring < 2) ring = 2;
+  }
+  w->ring = ring;
   if (nf > 0) {
-    HIP_OK(w, hipMalloc(&d_in, in_frame * nf));
-    HIP_OK(w, hipMalloc(&d_out, out_frame * nf));
-    if (o->pipeline == 0 || o->pipeline == 3) HIP_OK(w, hipMalloc(&d_mid, out_frame * nf));
+    HIP_OK(w, hipMalloc(&w->d_in, in_frame * nf * ring));
+    HIP_OK(w, hipMalloc(&w->d_out, out_frame * nf * ring));
+    if (needs_mid) HIP_OK(w, hipMalloc(&w->d_mid, out_frame * nf * ring));
     uint16_t* host = (uint16_t*)malloc(in_frame);
-    if (!host) { snprintf(w->error, sizeof w->error, "out of host memory"); w->status = -1; return NULL; }
-    for (int f = 0; f < nf; ++f) {
-      synth_frame(host, o->in_w, o->in_h, f0 + f);
-      HIP_OK(w, hipMemcpy((char*)d_in + in_frame * f, host, in_frame, hipMemcpyHostToDevice));
-    }
+    if (!host) { snprintf(w->error, sizeof w->error, "out of host memory"); w->status = -1; return -1; }
+    for (int s = 0; s < ring; ++s)
+      for (int f = 0; f < nf; ++f) {
+        synth_frame(host, o->in_w, o->in_h, f0 + f + 1000 * s);  /* every set holds different frames */
+        hipError_t e = hipMemcpy((char*)w->d_in + in_frame * ((size_t)s * nf + f), host, in_frame, hipMemcpyHostToDevice);
+        if (e != hipSuccess) { free(host); HIP_OK(w, e); }
+      }
     free(host);
   }
-  fsr1_image in = {d_in, o->in_w, o->in_h, FSR1_FORMAT_RGBA16F, nf, 0, 0};
-  fsr1_image mid = {d_mid, o->out_w, o->out_h, FSR1_FORMAT_RGBA16F, nf, 0, 0};
-  fsr1_image out = {d_out, o->out_w, o->out_h, FSR1_FORMAT_RGBA16F, nf, 0, 0};
   /* tiled noise for the colour stages: rgb = signed grain in [-0.5, 0.5), a = dither in [0, 1) */
   enum { NOISE_W = 128, NOISE_H = 128, NOISE_S = 4 };
-  void* d_noise = NULL;
   fsr1_image noise = {NULL, NOISE_W, NOISE_H, FSR1_FORMAT_RGBA16F, NOISE_S, 0, 0};
   fsr1_color_stages stages = {o->stages, o->grain, 0.0f, 0u, 0, 0, NULL};
   if (o->stages & (FSR1_COLOR_LFGA | FSR1_COLOR_DITHER_FROM_NOISE)) {
     const size_t n = (size_t)NOISE_W * NOISE_H * NOISE_S;
     uint16_t* hn = (uint16_t*)malloc(n * 8);
-    if (!hn) { snprintf(w->error, sizeof w->error, "out of host memory"); w->status = -1; return NULL; }
+    if (!hn) { snprintf(w->error, sizeof w->error, "out of host memory"); w->status = -1; return -1; }
     for (size_t i = 0; i < n; ++i)
       for (int c = 0; c < 4; ++c) {
         const float u = (float)(mix32((uint32_t)i, (uint32_t)c, 0xC0FFEEu) >> 8) * (1.0f / 16777216.0f);
         hn[i * 4 + c] = half_from_float(c < 3 ? u - 0.5f : u);
       }
-    HIP_OK(w, hipMalloc(&d_noise, n * 8));
-    HIP_OK(w, hipMemcpy(d_noise, hn, n * 8, hipMemcpyHostToDevice));
+    hipError_t e = hipMalloc(&w->d_noise, n * 8);
+    if (e == hipSuccess) e = hipMemcpy(w->d_noise, hn, n * 8, hipMemcpyHostToDevice);
     free(hn);
-    noise.data = d_noise;
+    HIP_OK(w, e);
+    noise.data = w->d_noise;
     stages.noise = &noise;
   }
   fsr1_params p;
@@ -183,38 +203,51 @@ static void* worker(void* arg) {
   p.fused = o->pipeline == 1 ? 1 : (o->pipeline == 3 ? 2 : 0);
   p.flags = o->math;
 
-  hipEvent_t ev0, ev1;
-  HIP_OK(w, hipEventCreate(&ev0));
-  HIP_OK(w, hipEventCreate(&ev1));
+  HIP_OK(w, hipEventCreate(&w->ev0));
+  HIP_OK(w, hipEventCreate(&w->ev1));
   float ms = 0.f;
   if (nf > 0) {
-    for (int i = 0; i < o->warmup; ++i) FSR_OK(w, fsr1_upscale_ex(&in, d_mid ? &mid : NULL, &out, &p, &stages, stream));
-    HIP_OK(w, hipEventRecord(ev0, stream));
-    for (int i = 0; i < o->steps; ++i) {
-      stages.frame = (uint32_t)i; /* the grain / dither pattern changes every frame (ffx_fsr1.h:1006) */
-      FSR_OK(w, fsr1_upscale_ex(&in, d_mid ? &mid : NULL, &out, &p, &stages, stream));
+    for (int i = -o->warmup; i < o->steps; ++i) {
+      if (i == 0) HIP_OK(w, hipEventRecord(w->ev0, stream));
+      const size_t s = (size_t)((i + o->warmup) % ring) * (size_t)nf;
+      fsr1_image in = {(char*)w->d_in + in_frame * s, o->in_w, o->in_h, FSR1_FORMAT_RGBA16F, nf, 0, 0};
+      fsr1_image mid = {w->d_mid ? (char*)w->d_mid + out_frame * s : NULL, o->out_w, o->out_h, FSR1_FORMAT_RGBA16F, nf, 0, 0};
+      fsr1_image out = {(char*)w->d_out + out_frame * s, o->out_w, o->out_h, FSR1_FORMAT_RGBA16F, nf, 0, 0};
+      stages.frame = (uint32_t)(i < 0 ? 0 : i); /* the grain / dither pattern changes every frame (ffx_fsr1.h:1006) */
+      FSR_OK(w, fsr1_upscale_ex(&in, w->d_mid ? &mid : NULL, &out, &p, &stages, stream));
     }
-    HIP_OK(w, hipEventRecord(ev1, stream));
-    HIP_OK(w, hipEventSynchronize(ev1));
-    HIP_OK(w, hipEventElapsedTime(&ms, ev0, ev1));
+    HIP_OK(w, hipEventRecord(w->ev1, stream));
+    HIP_OK(w, hipEventSynchronize(w->ev1));
+    HIP_OK(w, hipEventElapsedTime(&ms, w->ev0, w->ev1));
   }
   w->counters[0] = (uint64_t)nf * (uint64_t)o->steps;
   w->counters[1] = w->counters[0] * (uint64_t)o->out_w * (uint64_t)o->out_h;
   w->counters[2] = (uint64_t)((double)ms * 1e6);
+  HIP_OK(w, hipMalloc((void**)&w->d_send, sizeof w->counters));
+  HIP_OK(w, hipMalloc((void**)&w->d_recv, sizeof w->counters * o->gpus));
+  HIP_OK(w, hipMemcpyAsync(w->d_send, w->counters, sizeof w->counters, hipMemcpyHostToDevice, stream));
+  return 0;
+}
 
-  /* the one collective: all-gather of 3 x uint64 per GPU over RCCL */
-  uint64_t *d_send = NULL, *d_recv = NULL;
-  HIP_OK(w, hipMalloc((void**)&d_send, sizeof w->counters));
-  HIP_OK(w, hipMalloc((void**)&d_recv, sizeof w->counters * o->gpus));
-  HIP_OK(w, hipMemcpyAsync(d_send, w->counters, sizeof w->counters, hipMemcpyHostToDevice, stream));
-  NCCL_OK(w, ncclAllGather(d_send, d_recv, 3, ncclUint64, w->comm, stream));
-  HIP_OK(w, hipStreamSynchronize(stream));
-  if (w->rank == 0) HIP_OK(w, hipMemcpy(w->gathered, d_recv, sizeof w->counters * o->gpus, hipMemcpyDeviceToHost));
+/* the one collective: all-gather of 3 x uint64 per GPU over RCCL */
+static int worker_collective(worker_t* w) {
+  const options_t* o = w->opt;
+  NCCL_OK(w, ncclAllGather(w->d_send, w->d_recv, 3, ncclUint64, w->comm, w->stream));
+  HIP_OK(w, hipStreamSynchronize(w->stream));
+  if (w->rank == 0) HIP_OK(w, hipMemcpy(w->gathered, w->d_recv, sizeof w->counters * o->gpus, hipMemcpyDeviceToHost));
+  return 0;
+}
 
-  (void)hipFree(d_send); (void)hipFree(d_recv);
-  (void)hipFree(d_in); (void)hipFree(d_mid); (void)hipFree(d_out); (void)hipFree(d_noise);
-  (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1);
-  (void)hipStreamDestroy(stream);
+static void* worker(void* arg) {
+  worker_t* w = (worker_t*)arg;
+  if (worker_body(w) != 0) atomic_store(&g_abort, 1);
+  pthread_barrier_wait(&g_before_collective);  /* every rank arrives, failed or not */
+  if (!atomic_load(&g_abort)) (void)worker_collective(w);
+  (void)hipFree(w->d_send); (void)hipFree(w->d_recv);
+  (void)hipFree(w->d_in); (void)hipFree(w->d_mid); (void)hipFree(w->d_out); (void)hipFree(w->d_noise);
+  if (w->ev0) (void)hipEventDestroy(w->ev0);
+  if (w->ev1) (void)hipEventDestroy(w->ev1);
+  if (w->stream) (void)hipStreamDestroy(w->stream);
   return NULL;
 }
 
@@ -222,13 +255,14 @@ static int parse_size(const char* s, int* w, int* h) { return sscanf(s, "%dx%d",
 
 static void usage(void) {
   puts("usage: fsr1_runner [--gpus N] [--frames F] [--in WxH] [--out WxH] [--steps K] [--warmup W]\n"
-       "                   [--pipeline two-pass|fused|easu|auto] [--math f|exact] [--sharpness STOPS] [--hdr]\n"
+       "                   [--pipeline two-pass|fused|easu|auto] [--math f|exact|h] [--sharpness STOPS] [--hdr]\n"
        "                   [--stages BITS] [--grain AMOUNT]   (colour stages: 1 SRTM, 2 grain, 4 SRTM inverse, 8/16 TEPD 8/10-bit)\n"
+       "                   [--ring R]   (frame sets to rotate over; default: enough to exceed the 256 MiB Infinity Cache)\n"
        "defaults: 1 GPU, 1 frame per GPU, 1920x1080 -> 3840x2160, 100 steps, 10 warmup, two-pass, f, 0.25 stops");
 }
 
 int main(int argc, char** argv) {
-  options_t o = {1, 0, 1920, 1080, 3840, 2160, 100, 10, 0, 0, 0u, 0.25f, 0u, 0.25f};
+  options_t o = {1, 0, 1920, 1080, 3840, 2160, 100, 10, 0, 0, 0u, 0.25f, 0u, 0.25f, 0};
   for (int i = 1; i < argc; ++i) {
     const char* a = argv[i];
     const char* v = i + 1 < argc ? argv[i + 1] : NULL;
@@ -242,6 +276,7 @@ int main(int argc, char** argv) {
     else if (!strcmp(a, "--sharpness")) { o.sharpness = (float)atof(v); ++i; }
     else if (!strcmp(a, "--stages")) { o.stages = (uint32_t)strtoul(v, NULL, 0); ++i; }
     else if (!strcmp(a, "--grain")) { o.grain = (float)atof(v); ++i; }
+    else if (!strcmp(a, "--ring")) { o.ring = atoi(v); ++i; }
     else if (!strcmp(a, "--in")) { if (!parse_size(v, &o.in_w, &o.in_h)) { fprintf(stderr, "bad --in %s\n", v); return 2; } ++i; }
     else if (!strcmp(a, "--out")) { if (!parse_size(v, &o.out_w, &o.out_h)) { fprintf(stderr, "bad --out %s\n", v); return 2; } ++i; }
     else if (!strcmp(a, "--pipeline")) {
@@ -251,6 +286,7 @@ int main(int argc, char** argv) {
       ++i;
     } else if (!strcmp(a, "--math")) {
       if (!strcmp(v, "f")) o.math = 0; else if (!strcmp(v, "exact")) o.math = FSR1_FLAG_MATH_EXACT;
+      else if (!strcmp(v, "h")) o.math = FSR1_FLAG_MATH_PACKED_FP16;
       else { fprintf(stderr, "bad --math %s\n", v); return 2; }
       ++i;
     } else { fprintf(stderr, "unknown option %s\n", a); usage(); return 2; }
@@ -258,7 +294,12 @@ int main(int argc, char** argv) {
   if (o.gpus < 1 || o.steps < 1 || o.warmup < 0) { usage(); return 2; }
   if (o.frames <= 0) o.frames = o.gpus; /* one frame per GPU */
   const int visible = fsr1_device_count();
-  if (visible < o.gpus) { fprintf(stderr, "need %d GPUs, %d visible (%s)\n", o.gpus, visible, visible < 0 ? fsr1_last_error() : "ok"); return 1; }
+  if (visible < 0) { fprintf(stderr, "cannot enumerate GPUs: %s\n", fsr1_last_error()); return 1; }
+  if (visible < o.gpus) { fprintf(stderr, "need %d GPUs, %d visible\n", o.gpus, visible); return 1; }
+  if ((o.math & FSR1_FLAG_MATH_PACKED_FP16) && (o.pipeline == 1 || o.stages)) {
+    fprintf(stderr, "--math h (FsrEasuH / FsrRcasH) runs as two dispatches without colour stages\n");
+    return 2;
+  }
 
   ncclComm_t* comms = (ncclComm_t*)calloc((size_t)o.gpus, sizeof *comms);
   int* devs = (int*)calloc((size_t)o.gpus, sizeof *devs);
@@ -269,6 +310,8 @@ int main(int argc, char** argv) {
   worker_t* ws = (worker_t*)calloc((size_t)o.gpus, sizeof *ws);
   pthread_t* th = (pthread_t*)calloc((size_t)o.gpus, sizeof *th);
   uint64_t* gathered = (uint64_t*)calloc((size_t)o.gpus * 3, sizeof *gathered);
+  atomic_init(&g_abort, 0);
+  pthread_barrier_init(&g_before_collective, NULL, (unsigned)o.gpus);
   for (int i = 0; i < o.gpus; ++i) {
     ws[i].opt = &o; ws[i].rank = i; ws[i].comm = comms[i]; ws[i].gathered = gathered;
     pthread_create(&th[i], NULL, worker, &ws[i]);
@@ -289,13 +332,14 @@ int main(int argc, char** argv) {
     const double bytes = (double)frames * (double)(o.pipeline == 0 ? in_b + 3 * out_b : in_b + out_b);
     printf("{\"metric\": \"upscaled megapixels/sec\", \"value\": %.1f, \"unit\": \"Mpix/s\", \"n_gpus\": %d, \"frames\": %llu, "
            "\"steps\": %d, \"seconds\": %.6f, \"in\": \"%dx%d\", \"out\": \"%dx%d\", \"pipeline\": \"%s\", \"math\": \"%s\", \"color_stages\": %u, "
-           "\"algorithmic_GBps\": %.1f, \"hbm_peak_frac\": %.4f, \"per_gpu_ms\": [",
+           "\"algorithmic_GBps\": %.1f, \"hbm_peak_frac\": %.4f, \"rccl_ranks\": %d, \"ring\": %d, \"per_gpu_ms\": [",
            (double)pixels / sec / 1e6, o.gpus, (unsigned long long)frames, o.steps, sec, o.in_w, o.in_h, o.out_w, o.out_h,
-           o.pipeline == 0 ? "two-pass" : (o.pipeline == 1 ? "fused" : (o.pipeline == 2 ? "easu" : "auto")), o.math ? "exact" : "f", o.stages, bytes / sec / 1e9,
-           bytes / sec / 1e9 / (8000.0 * o.gpus));
+           o.pipeline == 0 ? "two-pass" : (o.pipeline == 1 ? "fused" : (o.pipeline == 2 ? "easu" : "auto")), o.math == FSR1_FLAG_MATH_EXACT ? "exact" : (o.math ? "h" : "f"), o.stages, bytes / sec / 1e9,
+           bytes / sec / 1e9 / (8000.0 * o.gpus), o.gpus, ws[0].ring);
     for (int i = 0; i < o.gpus; ++i) printf("%s%.3f", i ? ", " : "", (double)gathered[3 * i + 2] * 1e-6);
     printf("]}\n");
   }
+  pthread_barrier_destroy(&g_before_collective);
   for (int i = 0; i < o.gpus; ++i) ncclCommDestroy(comms[i]);
   free(comms); free(devs); free(ws); free(th); free(gathered);
   return rc;

@@ -44,3 +44,30 @@ def test_runner_with_colour_stages(runner):
     assert out.returncode == 0, out.stdout + out.stderr
     d = json.loads(out.stdout.strip().splitlines()[-1])
     assert d["color_stages"] == 7 and d["frames"] == 20 and d["value"] > 1000.0
+
+
+@pytest.mark.gpu
+def test_runner_packed_fp16_and_ring(runner):
+    """--math h drives FsrEasuH / FsrRcasH from the C host; --ring rotates the steps over several frame sets."""
+    out = subprocess.run([runner, "--gpus", "1", "--frames", "2", "--in", "640x360", "--out", "1280x720", "--steps", "12",
+                          "--warmup", "2", "--math", "h", "--ring", "3"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    d = json.loads(out.stdout.strip().splitlines()[-1])
+    assert d["math"] == "h" and d["ring"] == 3 and d["frames"] == 24 and d["value"] > 500.0
+    bad = subprocess.run([runner, "--math", "h", "--pipeline", "fused"], capture_output=True, text=True, timeout=60)
+    assert bad.returncode == 2
+
+
+@pytest.mark.gpu
+def test_runner_two_gpus_over_rccl(runner, fsr):
+    """N = 2: one host thread per GPU, frames sharded in contiguous blocks, the counters gathered over RCCL (skipped on a
+    single-GPU box: the driver's scaling run is the 8-GPU evidence)."""
+    import ctypes
+    if fsr.load().fsr1_device_count() < 2:
+        pytest.skip("needs two visible GPUs")
+    out = subprocess.run([runner, "--gpus", "2", "--frames", "5", "--in", "960x540", "--out", "1920x1080", "--steps", "20",
+                          "--warmup", "3"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    d = json.loads(out.stdout.strip().splitlines()[-1])
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["frames"] == 100 and len(d["per_gpu_ms"]) == 2
+    assert all(ms > 0 for ms in d["per_gpu_ms"])
