@@ -60,25 +60,32 @@ def reduce_counters(frames, pixels, seconds, device):
     return {"frames": int(round(s[0].item())), "pixels": int(round(s[1].item())), "seconds": float(m[0].item())}
 
 
-def pmc_traffic(workload, pipeline, kernel_name):
-    """HBM bytes per launch of `kernel_name` from the newest committed rocprofv3 PMC summary of this
-    workload/pipeline (profiles/*.json, written by tools/prof_summary.py from separate --pmc passes of this
-    very command; FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 correction, WRITE_SIZE as reported).
-    PMC counters cannot be collected from inside the timed run, so this is None when no summary matches."""
+def pmc_traffic(fsr, workload, pipeline, kernel_name, math="f", storage="rgba16f"):
+    """HBM bytes per launch of `kernel_name` from the committed rocprofv3 PMC summary of this very configuration
+    (profiles/*.json, written by tools/gpu_profile.sh -> tools/prof_summary.py from separate --pmc passes of this
+    command; FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 correction, WRITE_SIZE as reported).  PMC counters
+    cannot be collected from inside the timed run.  A summary is quoted only if it was taken of the kernel sources
+    that are running now (`source_hash` over csrc/ + include/): otherwise `traffic` is null and the stale file is named.
+    Returns (traffic_bytes or None, source path or None, SQ_INSTS_VALU or None, stale path or None)."""
     import glob
-    best = None
+    now = fsr._lib.source_hash()
+    best, stale = None, None
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*.json"))):
         try:
             d = json.load(open(f))
         except (OSError, ValueError):
             continue
-        if d.get("workload") != workload or d.get("pipeline") != pipeline:
+        if d.get("workload") != workload or d.get("pipeline") != pipeline or d.get("math", "f") != math or d.get("storage", "rgba16f") != storage:
             continue
         for k, v in d.get("kernels", {}).items():
-            if ("::%s_kernel<" % kernel_name) in k and "traffic_bytes" in v.get("hbm_per_launch", {}):
-                best = (v["hbm_per_launch"]["traffic_bytes"], os.path.relpath(f, ROOT),
-                        v.get("pmc_avg_per_launch", {}).get("SQ_INSTS_VALU"))
-    return best
+            if ("::%s%s_kernel<" % (kernel_name, "_h" if math == "h" else "")) in k + "<" and "traffic_bytes" in v.get("hbm_per_launch", {}):
+                if d.get("source_hash") != now:
+                    stale = os.path.relpath(f, ROOT)
+                    continue
+                best = (v["hbm_per_launch"]["traffic_bytes"], os.path.relpath(f, ROOT), v.get("pmc_avg_per_launch", {}).get("SQ_INSTS_VALU"))
+    if best:
+        return best + (None,)
+    return (None, None, None, stale)
 
 
 def cpu_baseline(fsr, in_w, in_h, out_w, out_h, target_seconds=12.0):
@@ -129,8 +136,9 @@ def main():
                     help="FSR1_COLOR_* bits fused into the pipeline (SURVEY 8f-N4): 1 SRTM prologue, 2 film grain, 4 SRTM inverse, "
                          "8 / 16 TEPD 8-bit / 10-bit dither; e.g. 7 = the HDR chain, 10 = grain + 8-bit dither")
     ap.add_argument("--math", default="f", choices=["f", "exact", "h"], help="f: fp32 math (default); exact: reference op order; h: packed fp16")
-    ap.add_argument("--storage", default="rgba16f", choices=["rgba16f", "rgba8"],
-                    help="image format in HBM: rgba16f (BASELINE's 8 B/pixel) or rgba8 (UNORM, 4 B/pixel; SURVEY 8f-N2)")
+    ap.add_argument("--storage", default="rgba16f", choices=["rgba16f", "rgba8", "rgba32f"],
+                    help="image format in HBM: rgba16f (BASELINE's 8 B/pixel), rgba8 (UNORM, 4 B/pixel; SURVEY 8f-N2) or rgba32f "
+                         "(16 B/pixel: BASELINE configs[0], 'fp32 FsrEasuF' with the sample's SAMPLE_SLOW_FALLBACK view, FSR_Pass.glsl:40)")
     ap.add_argument("--graph", type=int, default=0,
                     help="capture this many consecutive steps into one hipGraph and replay it (launch-bound small frames, SURVEY H9); "
                          "--steps is rounded down to a multiple of it")
@@ -165,8 +173,8 @@ def main():
     math_flags = {"f": 0, "exact": fsr.FLAG_MATH_EXACT, "h": fsr.FLAG_MATH_PACKED_FP16}[args.math]
     if args.no_fast_paths:
         math_flags |= fsr.FLAG_NO_FAST_PATHS
-    px = 8 if args.storage == "rgba16f" else 4
-    tdtype = torch.float16 if args.storage == "rgba16f" else torch.uint8
+    px = {"rgba16f": 8, "rgba8": 4, "rgba32f": 16}[args.storage]
+    tdtype = {"rgba16f": torch.float16, "rgba8": torch.uint8, "rgba32f": torch.float32}[args.storage]
     if args.storage != "rgba16f" and args.math == "h":
         raise SystemExit("--math h (FsrEasuH/FsrRcasH) is defined on RGBA16F images")
     in_bytes, out_bytes = in_w * in_h * px * frames, out_w * out_h * px * frames
@@ -178,6 +186,8 @@ def main():
         f = fsr.frames.synthetic_frame(in_w, in_h, k=k + 16 * rank)
         if args.storage == "rgba8":
             f = np.floor(np.clip(f.astype(np.float32), 0.0, 1.0) * 255.0 + 0.5).astype(np.uint8)
+        elif args.storage == "rgba32f":
+            f = f.astype(np.float32)
         return torch.from_numpy(f).to(device)
 
     base = [upload(k) for k in range(min(frames, 2))]
@@ -277,6 +287,25 @@ def main():
         also = {"fused": {"value": round(tf["pixels"] / tf["seconds"] / 1e6, 1), "unit": "Mpix/s",
                           "ms_per_step": round(tf["seconds"] * 1e3 / args.steps, 5),
                           "note": "EASU->RCAS in one launch, output bit-identical to the two dispatches (BASELINE configs[3])"}}
+        if args.storage == "rgba16f" and args.math == "f":
+            # the reference's shipping default (FsrEasuH / FsrRcasH, FSR_Pass.hlsl:81-87) on the same frames, same K steps
+            hflags = fsr.FLAG_MATH_PACKED_FP16
+
+            def h_step(i):
+                fsr.easu(srcs[i % ring], mids[i % ring], con=easu_con, flags=hflags)
+                fsr.rcas(mids[i % ring], dsts[i % ring], con=rcas_con, flags=hflags)
+            for i in range(min(args.warmup, 50)):
+                h_step(i)
+            fence()
+            t0 = time.perf_counter()
+            for i in range(args.steps):
+                h_step(i)
+            fence()
+            th = reduce_counters(frames * args.steps, frames * args.steps * out_w * out_h, time.perf_counter() - t0, device)
+            also["packed_fp16_two_pass"] = {"value": round(th["pixels"] / th["seconds"] / 1e6, 1), "unit": "Mpix/s",
+                                            "ms_per_step": round(th["seconds"] * 1e3 / args.steps, 5),
+                                            "note": "FsrEasuH + FsrRcasH (parity class H: bit-exact vs the reference's packed-fp16 path; "
+                                                    "v_pk_*_f16 issue at half rate on MI355X, DESIGN.md 3.4)"}
 
     # ---- per-kernel durations with HIP events on the launch stream (C-ABI stopwatch) ----
     timer = fsr.Timer()
@@ -311,16 +340,18 @@ def main():
 
     def roof(name):
         gbps = alg[name] / (kern[name] * 1e-3) / 1e9
-        pmc = pmc_traffic(args.workload, args.pipeline, name) if args.math == "f" and args.storage == "rgba16f" and not args.stages else None
+        pmc = pmc_traffic(fsr, args.workload, args.pipeline, name, args.math, args.storage) if not args.stages and not args.no_fast_paths else (None, None, None, None)
         r = {"kernel": name, "bound": "hbm", "achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-             "frac": round(gbps / HBM_PEAK_GBPS, 4), "traffic": pmc[0] if pmc else None,
-             "traffic_source": pmc[1] if pmc else None, "algorithmic_bytes": alg[name],
+             "frac": round(gbps / HBM_PEAK_GBPS, 4), "traffic": pmc[0],
+             "traffic_source": pmc[1], "algorithmic_bytes": alg[name],
              "avg_kernel_us": round(kern[name] * 1e3, 2)}
+        if pmc[3]:
+            r["traffic_stale"] = "%s was taken of other kernel sources (source_hash differs): not quoted" % pmc[3]
         if name in ("easu", "fused"):
             # the north star's "HBM read-roofline": input bytes only (SURVEY.md 8d asks for both figures, labelled)
             rd = in_bytes / (kern[name] * 1e-3) / 1e9
             r["read_only"] = {"achieved": round(rd, 1), "frac": round(rd / HBM_PEAK_GBPS, 4), "algorithmic_bytes": in_bytes}
-        if pmc and pmc[2]:
+        if pmc[2]:
             # the wall this kernel is actually on: VALU issue (wave-instructions per launch from the same PMC summary,
             # SQ_INSTS_VALU, over the live kernel time)
             gi = pmc[2] / (kern[name] * 1e-3) / 1e9
@@ -331,7 +362,7 @@ def main():
     if rank == 0:
         line = {
             "metric": {"easu": "upscaled megapixels/sec (EASU only)", "color": "megapixels/sec (colour pass)"}.get(
-                args.pipeline, "upscaled megapixels/sec (EASU+RCAS, 1080p->4K fp16)"),
+                args.pipeline, "upscaled megapixels/sec (EASU+RCAS, %s fp16)" % ("1080p->4K" if args.workload == "1080p_to_4k" else args.workload)),
             "value": round(value, 1), "unit": "Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(total["seconds"] * 1e3 / args.steps, 5), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": round(value / world / PUBLISHED_4K_MPIX_S, 2) if (out_w, out_h) == (3840, 2160) and args.pipeline in ("two-pass", "fused") and not args.stages else None,
@@ -340,6 +371,7 @@ def main():
             "dtype": "f32" if args.math != "h" else "f16", "data": "synthetic",
             "config": {"workload": "%s: %dx%d -> %dx%d %s, %d frame(s)/step/GPU, %s, math=%s, ring of %d frame sets"
                                    % (args.workload, in_w, in_h, out_w, out_h, args.storage.upper(), frames, args.pipeline, args.math, ring),
+                       "source_hash": fsr._lib.source_hash(),
                        "pipeline": args.pipeline, "storage": args.storage, "color_stages": args.stages, "hip_graph_steps": args.graph, "rcas_sharpness_stops": 0.25,
                        "parallelism": "independent frames per GPU, counters-only collective"},
             "roofline": roof(dominant),

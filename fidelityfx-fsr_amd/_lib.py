@@ -84,6 +84,21 @@ SYMBOLS = {
 _lib = None
 
 
+def source_hash():
+    """sha256 (first 16 hex digits) over the kernel sources the library is built from (csrc/ + include/): what a profile
+    under profiles/ was taken of.  bench.py compares it with the running tree before quoting a profile's PMC traffic."""
+    import hashlib
+    h = hashlib.sha256()
+    root = os.path.dirname(_HERE)
+    files = []
+    for d, exts in ((os.path.join(_HERE, "csrc"), (".hip", ".h", ".c", "Makefile")), (os.path.join(root, "include"), (".h", ".hpp"))):
+        files += [os.path.join(d, f) for f in os.listdir(d) if f.endswith(exts)]
+    for f in sorted(files):
+        h.update(os.path.basename(f).encode() + b"\0")
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def build(force=False):
     """Compile every HIP translation unit for gfx950 (hipcc cross-compiles without a GPU)."""
     cmd = ["make", "-C", os.path.join(_HERE, "csrc"), "-j8"]

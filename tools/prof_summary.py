@@ -113,6 +113,10 @@ def main():
     ap.add_argument("--command", default="")
     ap.add_argument("--workload", default="", help="bench.py --workload this profile belongs to (lets bench.py find its PMC traffic)")
     ap.add_argument("--pipeline", default="", help="bench.py --pipeline this profile belongs to")
+    ap.add_argument("--math", default="f")
+    ap.add_argument("--storage", default="rgba16f")
+    ap.add_argument("--lib", default="", help="the shared library profiled: per-kernel VGPR / SGPR / static LDS / scratch are read from its code objects")
+    ap.add_argument("--bench-line", default="", help="file holding the JSON line bench.py printed during the kernel-trace pass")
     a = ap.parse_args()
 
     kernels = read_stats(a.stats)
@@ -138,7 +142,33 @@ def main():
         if "SQ_INSTS_VALU" in p and "avg_us" in v:
             # wave-instructions per SIMD per microsecond: 1024 SIMDs; a plain v_fma_f32 stream peaks at ~1000/us (2.4 cyc @2.4 GHz)
             v["valu_wave_insts_per_simd_per_us"] = round(p["SQ_INSTS_VALU"] / 1024.0 / v["avg_us"], 1)
-    doc = {"command": a.command, "note": a.note, "workload": a.workload, "pipeline": a.pipeline, "kernels": kernels}
+    if a.lib:
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("kernel_meta", os.path.join(os.path.dirname(os.path.abspath(__file__)), "kernel_meta.py"))
+        km = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(km)
+        meta = km.kernel_meta(a.lib)
+        for k, v in kernels.items():
+            if k in meta:
+                v["profiler_reported"] = {x: v.get(x) for x in ("vgpr", "sgpr", "lds_bytes", "scratch") if x in v}
+                v.update({"vgpr": meta[k]["vgpr"], "sgpr": meta[k]["sgpr"], "lds_static_bytes": meta[k]["lds_static_bytes"],
+                          "scratch": meta[k]["scratch_bytes"], "vgpr_spills": meta[k]["vgpr_spills"], "registers_from": "code object metadata"})
+    doc = {"command": a.command, "note": a.note, "workload": a.workload, "pipeline": a.pipeline, "math": a.math, "storage": a.storage, "kernels": kernels}
+    try:
+        import importlib
+        import sys
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        doc["source_hash"] = importlib.import_module("fidelityfx-fsr_amd._lib").source_hash()
+    except Exception as e:  # the summary is still useful without it; bench.py will then treat the profile as stale
+        doc["source_hash"] = None
+        doc["source_hash_error"] = str(e)
+    if a.bench_line and os.path.exists(a.bench_line):
+        for line in open(a.bench_line):
+            if line.startswith("{"):
+                try:
+                    doc["bench_line"] = json.loads(line)
+                except ValueError:
+                    pass
     os.makedirs(os.path.dirname(a.out) or ".", exist_ok=True)
     with open(a.out + ".json", "w") as f:
         json.dump(doc, f, indent=1, sort_keys=True)
@@ -148,14 +178,16 @@ def main():
             f.write("Command: `%s`\n\n" % a.command)
         if a.note:
             f.write(a.note + "\n\n")
-        f.write("| kernel | calls | avg us | min us | max us | VGPR | SGPR | LDS B | fetch MB (x2 corrected) | write MB | L2 hit | VALU insts/wave |\n")
+        if doc.get("source_hash"):
+            f.write("Kernel sources (csrc/ + include/) sha256[:16] = `%s`; VGPR / SGPR / static LDS from the code-object metadata of the profiled library.\n\n" % doc["source_hash"])
+        f.write("| kernel | calls | avg us | min us | max us | VGPR | SGPR | static LDS B | fetch MB (x2 corrected) | write MB | L2 hit | VALU insts/wave |\n")
         f.write("|---|---|---|---|---|---|---|---|---|---|---|---|\n")
         for k in sorted(kernels):
             v = kernels[k]
             h = v.get("hbm_per_launch", {})
             f.write("| `%s` | %s | %s | %s | %s | %s | %s | %s | %s | %s | %s | %s |\n" % (
                 k, v.get("calls", ""), v.get("avg_us", ""), v.get("min_us", ""), v.get("max_us", ""), v.get("vgpr", ""),
-                v.get("sgpr", ""), v.get("lds_bytes", ""),
+                v.get("sgpr", ""), v.get("lds_static_bytes", v.get("lds_bytes", "")),
                 round(h["fetch_bytes_corrected"] / 1e6, 2) if "fetch_bytes_corrected" in h else "",
                 round(h["write_bytes"] / 1e6, 2) if "write_bytes" in h else "",
                 v.get("l2_hit_rate", ""), v.get("valu_insts_per_wave", "")))
