@@ -17,7 +17,7 @@ hipError_t rcas_launch(const RcasArgs& a, int fmt, bool exact, hipStream_t strea
 void rcas_geometry(int width, int height, int frames, int* tiles_x, int* tiles_y, int* rows);
 hipError_t fused_launch(const FusedArgs& a, int fmt, bool exact, hipStream_t stream);
 size_t fused_lds_bytes(int fmt, int fp_w, int fp_h);
-hipError_t easu_h_launch(const EasuArgs& a, hipStream_t stream);
+hipError_t easu_h_launch(const EasuArgs& a, bool s2, hipStream_t stream);
 hipError_t easu_color_launch(const EasuArgs& a, int fin, int fout, bool exact, hipStream_t stream);
 hipError_t rcas_color_launch(const RcasArgs& a, int fin, int fout, bool exact, hipStream_t stream);
 hipError_t fused_color_launch(const FusedArgs& a, int fin, int fout, bool exact, hipStream_t stream);
@@ -222,7 +222,7 @@ int fsr1_easu_dispatch_ex(const fsr1_image* in, const fsr1_image* out, const uin
   // out = 2 * in — takes the variant whose lanes own 2x2 output quads; its tiles are shifted by one pixel, hence one
   // more tile per axis when the size is a multiple of the tile, and the footprint of a tile is 64/2+3 x 16/2+3 texels.
   const bool s2 = con[0] == 0x3f000000u && con[1] == 0x3f000000u && con[2] == 0xbe800000u && con[3] == 0xbe800000u &&
-                  !(flags & (FSR1_FLAG_NO_FAST_PATHS | FSR1_FLAG_MATH_PACKED_FP16)) && !a.color.stages && kTileH % 16 == 0;
+                  !(flags & FSR1_FLAG_NO_FAST_PATHS) && !a.color.stages && kTileH % 16 == 0;
   if (s2) {
     a.tiles_x = (out->width + 1 + kTileW - 1) / kTileW;
     a.tiles_y = (out->height + 1 + kTileH - 1) / kTileH;
@@ -233,7 +233,7 @@ int fsr1_easu_dispatch_ex(const fsr1_image* in, const fsr1_image* out, const uin
   hipError_t e;
   if (flags & FSR1_FLAG_MATH_PACKED_FP16) {
     if (in->format != FSR1_FORMAT_RGBA16F) return fail(FSR1_ERR_UNSUPPORTED, "easu: packed-fp16 math needs RGBA16F images");
-    e = easu_h_launch(a, static_cast<hipStream_t>(stream));
+    e = easu_h_launch(a, s2, static_cast<hipStream_t>(stream));
   } else if (a.color.stages) {
     e = easu_color_launch(a, in->format, out->format, (flags & FSR1_FLAG_MATH_EXACT) != 0, static_cast<hipStream_t>(stream));
   } else {

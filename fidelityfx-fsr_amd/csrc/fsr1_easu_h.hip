@@ -32,9 +32,91 @@ struct EasuHLds {
   uint4* both;
 };
 
+// Phases 1 and 2 of the H kernel for the footprint [fx0, fx0+fw) x [fy0, fy0+fh).  FW, FH: compile-time extent (exact 2x).
+template <int FW, int FH>
+__device__ __forceinline__ void easu_h_stage(const EasuHLds& l, const ImageView& in, const char* in_frame, int fx0, int fy0, int fw_rt, int fh_rt, int tid) {
+  const int fw = FW ? FW : fw_rt, fh = FH ? FH : fh_rt;
+  const int n = fw * fh - 1;  // the bottom-right corner texel is touched by no 12-tap window (no (2, 2) tap)
+  const float inv_fw = 1.0f / (float)fw;
+  auto row_of = [&](int i) { return FW ? i / FW : (int)(((float)i + 0.5f) * inv_fw); };
+  {  // ---- phase 1: HBM -> LDS (clamp-to-edge applied), luma once per input texel; row base + 32-bit lane offsets ----
+    const int gy0 = min(max(fy0, 0), in.height - 1);
+    const char* const base = in_frame + (long long)gy0 * in.pitch;
+    const uint32_t pitch = (uint32_t)in.pitch;
+    const half_t hlf = (half_t)0.5f;
+    auto stage = [&](int i, uint32_t off) {
+      const half4_t c = *reinterpret_cast<const half4_t*>(base + (size_t)off);
+      l.tex1[i] = half4_t{c.x, c.y, c.z, (half_t)(c.z * hlf + (c.x * hlf + c.y))};  // :535-538
+    };
+    if (fx0 >= 0 && fy0 >= 0 && fx0 + fw <= in.width && fy0 + fh <= in.height) {  // wave-uniform: nothing to clamp
+      const uint32_t x_off = (uint32_t)fx0 * 8u;
+      for (int i = tid; i < n; i += kThreads) {
+        const int ly = row_of(i);
+        stage(i, (uint32_t)ly * pitch + (uint32_t)(i - ly * fw) * 8u + x_off);
+      }
+    } else {
+      for (int i = tid; i < n; i += kThreads) {
+        const int ly = row_of(i);
+        const int gy = min(max(fy0 + ly, 0), in.height - 1);
+        const int gx = min(max(fx0 + (i - ly * fw), 0), in.width - 1);
+        stage(i, (uint32_t)(gy - gy0) * pitch + (uint32_t)gx * 8u);
+      }
+    }
+  }
+  __syncthreads();
+  // ---- phase 2a: (texel, right neighbour) pairs — read as the left element by taps in columns 0 .. fw-2 of every row
+  //      (an entry in the last column pairs with the next row's first texel and is never read) ----
+  for (int i = tid; i < n - 1; i += kThreads) {
+    const half4_t tc = l.tex1[i], tr = l.tex1[i + 1];
+    l.texP[i] = uint4{as_u(h2(tc.x, tr.x)), as_u(h2(tc.y, tr.y)), as_u(h2(tc.z, tr.z)), as_u(h2(tc.w, tr.w))};
+  }
+  // ---- phase 2b: per-texel terms of the texels read as f / g / j / k of some pixel: columns 1..fw-2, rows 1..fh-2
+  //      (every neighbour of those lies inside the footprint, so nothing is clamped) ----
+  const int iw = fw - 2, m = iw * (fh - 2);
+  const float inv_iw = 1.0f / (float)iw;
+  for (int j = tid; j < m; j += kThreads) {
+    const int y = FW ? j / (FW - 2) : (int)(((float)j + 0.5f) * inv_iw);
+    const int i = (y + 1) * fw + (j - y * iw) + 1;
+    const half4_t tc = l.tex1[i], tr = l.tex1[i + 1], td = l.tex1[i + fw];
+    l.ana1[i] = easu_analysis_h(l.tex1[i - fw].w, l.tex1[i - 1].w, tc.w, tr.w, td.w);  // FsrEasuSetH :486-502, one AH2 lane
+    if (i + fw + 1 < n) {  // the 2x2 block at the last interior texel would reach the unstaged corner; no pixel has that texel as 'f'
+      const half4_t tdr = l.tex1[i + fw + 1];
+      // :575-577 min and max of the 2x2 block f g / j k through max() of (-x, x) pairs
+      const half2_t bR = easu_both_h(tc.x, tr.x, td.x, tdr.x), bG = easu_both_h(tc.y, tr.y, td.y, tdr.y), bB = easu_both_h(tc.z, tr.z, td.z, tdr.z);
+      l.both[i] = uint4{as_u(bR), as_u(bG), as_u(bB), 0u};
+    }
+  }
+  __syncthreads();
+}
+
+// FsrEasuH for the pixel whose 'f' texel sits at footprint index f, sub-texel position ppp (= AH2(pp), :516).
+__device__ __forceinline__ half4_t easu_h_pixel(const EasuHLds& l, int f, int fw, half2_t ppp, bool hdr) {
+  // texP[t] holds (t, t+1), so the reference's pairs bc / ij / kl come as stored and fe / hg / on are the swapped
+  // (e,f) / (g,h) / (n,o)
+  const uint4 bo = l.both[f];
+  const rgbh_t px = easu_filter_h(
+      [&](int k) { return l.ana1[f + (k >> 1) * fw + (k & 1)]; },
+      [&](int i) {
+        const int at[6] = {f - fw, f + fw - 1, f - 1, f + fw + 1, f + 1, f + 2 * fw};
+        const uint4 t = l.texP[at[i]];
+        const bool sw = i == 2 || i == 4 || i == 5;
+        return sw ? EasuHPair{swap2(as_h2(t.x)), swap2(as_h2(t.y)), swap2(as_h2(t.z))} : EasuHPair{as_h2(t.x), as_h2(t.y), as_h2(t.z)};
+      },
+      [&](int c) { return as_h2(c == 0 ? bo.x : (c == 1 ? bo.y : bo.z)); }, ppp);
+  half_t pr = px.r, pg = px.g, pb = px.b;
+  if (hdr) { pr = pr * pr; pg = pg * pg; pb = pb * pb; }  // FSR_Pass.hlsl:78-79
+  return half4_t{pr, pg, pb, (half_t)1.0f};              // alpha = 1, FSR_Pass.hlsl:80
+}
+
+// S2: exactly 2x with the viewport covering the input (con0 = {1/2, 1/2, -1/4, -1/4}): a lane owns the 2x2 output quad
+// that shares one 12-tap window, tiles are shifted by one pixel, the footprint is a compile-time 35 x 11 and the
+// sub-texel positions are the constants 1/4 and 3/4 — see easu_kernel in fsr1_easu_kernel.h.  Same binary16 operations
+// on the same values as the generic variant: bit-identical.
+template <bool S2>
 __global__ void __launch_bounds__(kThreads) easu_h_kernel(const EasuArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int cap = a.fp_w * a.fp_h;
+  constexpr int kS2W = kTileW / 2 + 3, kS2H = kTileH / 2 + 3;
+  const int cap = S2 ? kS2W * kS2H : a.fp_w * a.fp_h;
   EasuHLds l;
   l.texP = reinterpret_cast<uint4*>(smem);
   l.both = reinterpret_cast<uint4*>(smem + (size_t)cap * 16);
@@ -46,46 +128,53 @@ __global__ void __launch_bounds__(kThreads) easu_h_kernel(const EasuArgs a) {
   const int frame = t / tiles_per_frame;
   const int tf = t - frame * tiles_per_frame;
   const int ty = tf / a.tiles_x, tx = tf - ty * a.tiles_x;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const char* const in_frame = a.in.base + (long long)frame * a.in.frame_stride;
+  const bool hdr = (a.flags & FSR1_FLAG_HDR_SQUARE) != 0;
+
+  if constexpr (S2) {
+    static_assert(kTileW == 64 && kTileH == 16, "the exact-2x variant is built for 64 x 16 tiles");
+    const int ox0 = tx * kTileW - 1, oy0 = ty * kTileH - 1;
+    easu_h_stage<kS2W, kS2H>(l, a.in, in_frame, tx * (kTileW / 2) - 2, ty * (kTileH / 2) - 2, kS2W, kS2H, tid);
+    const int W = a.out.width, H = a.out.height;
+    const int qx = lane & 31, qy = 2 * wave + (lane >> 5);
+    const int oxa = ox0 + 2 * qx, oya = oy0 + 2 * qy;  // odd: the quad is {oxa, oxa+1} x {oya, oya+1}
+    const bool xin0 = oxa >= 0 && oxa < W, xin1 = oxa + 1 < W, yin0 = oya >= 0 && oya < H, yin1 = oya + 1 < H;
+    if (!((xin0 || xin1) && (yin0 || yin1))) return;
+    const int f = (qy + 1) * kS2W + (qx + 1);
+    char* const o0 = a.out.base + (long long)frame * a.out.frame_stride + (long long)oya * a.out.pitch + (long long)oxa * 8;
+    const half_t q1 = (half_t)0.25f, q3 = (half_t)0.75f;
+    struct __attribute__((aligned(8))) pair_t { half4_t p[2]; };
+    if (xin0 && xin1 && yin0 && yin1) {
+      pair_t r0, r1;
+      r0.p[0] = easu_h_pixel(l, f, kS2W, h2(q1, q1), hdr);
+      r0.p[1] = easu_h_pixel(l, f, kS2W, h2(q3, q1), hdr);
+      r1.p[0] = easu_h_pixel(l, f, kS2W, h2(q1, q3), hdr);
+      r1.p[1] = easu_h_pixel(l, f, kS2W, h2(q3, q3), hdr);
+      *reinterpret_cast<pair_t*>(o0) = r0;
+      *reinterpret_cast<pair_t*>(o0 + a.out.pitch) = r1;
+      return;
+    }
+    auto row = [&](char* o, bool yin, half_t ppy) {
+      if (!yin) return;
+      if (xin0) *reinterpret_cast<half4_t*>(o) = easu_h_pixel(l, f, kS2W, h2(q1, ppy), hdr);
+      if (xin1) *reinterpret_cast<half4_t*>(o + 8) = easu_h_pixel(l, f, kS2W, h2(q3, ppy), hdr);
+    };
+    row(o0, yin0, q1);
+    row(o0 + a.out.pitch, yin1, q3);
+    return;
+  }
+
   const int ox0 = tx * kTileW, oy0 = ty * kTileH;
   const float c0x = as_f32(a.con[0]), c0y = as_f32(a.con[1]), c0z = as_f32(a.con[2]), c0w = as_f32(a.con[3]);
-
   const int oxl = min(ox0 + kTileW, a.out.width) - 1, oyl = min(oy0 + kTileH, a.out.height) - 1;
   const int fx0 = (int)floorf((float)ox0 * c0x + c0z) - 1;
   const int fy0 = (int)floorf((float)oy0 * c0y + c0w) - 1;
   const int fw = min((int)floorf((float)oxl * c0x + c0z) + 2 - fx0 + 1, a.fp_w);
   const int fh = min((int)floorf((float)oyl * c0y + c0w) + 2 - fy0 + 1, a.fp_h);
+  easu_h_stage<0, 0>(l, a.in, in_frame, fx0, fy0, fw, fh, tid);
 
-  const int tid = threadIdx.x;
-  const int n = fw * fh;
-  const half_t one = (half_t)1.0f;
-  {  // ---- phase 1: HBM -> LDS (clamp-to-edge applied), luma once per input texel ----
-    const char* const in_frame = a.in.base + (long long)frame * a.in.frame_stride;
-    const float inv_fw = 1.0f / (float)fw;
-    for (int i = tid; i < n; i += kThreads) {
-      const int ly = (int)(((float)i + 0.5f) * inv_fw);
-      const int lx = i - ly * fw;
-      const int gy = min(max(fy0 + ly, 0), a.in.height - 1);
-      const int gx = min(max(fx0 + lx, 0), a.in.width - 1);
-      const half4_t c = *reinterpret_cast<const half4_t*>(in_frame + (long long)gy * a.in.pitch + (size_t)gx * sizeof(half4_t));
-      const half_t hlf = (half_t)0.5f;
-      l.tex1[i] = half4_t{c.x, c.y, c.z, (half_t)(c.z * hlf + (c.x * hlf + c.y))};  // :535-538
-    }
-  }
-  __syncthreads();
-  // ---- phase 2: per-texel terms (border texels read clamped neighbours and produce values nobody uses) ----
-  for (int i = tid; i < n; i += kThreads) {
-    const int iu = max(i - fw, 0), id = min(i + fw, n - 1), il = max(i - 1, 0), ir = min(i + 1, n - 1), idr = min(id + 1, n - 1);
-    const half4_t tc = l.tex1[i], tr = l.tex1[ir], td = l.tex1[id], tdr = l.tex1[idr];
-    const half_t lA = l.tex1[iu].w, lB = l.tex1[il].w, lC = tc.w, lD = tr.w, lE = td.w;
-    l.ana1[i] = easu_analysis_h(lA, lB, lC, lD, lE);  // FsrEasuSetH :486-502, one AH2 lane
-    l.texP[i] = uint4{as_u(h2(tc.x, tr.x)), as_u(h2(tc.y, tr.y)), as_u(h2(tc.z, tr.z)), as_u(h2(tc.w, tr.w))};
-    // :575-577 min and max of the 2x2 block f g / j k through max() of (-x, x) pairs
-    const half2_t bR = easu_both_h(tc.x, tr.x, td.x, tdr.x), bG = easu_both_h(tc.y, tr.y, td.y, tdr.y), bB = easu_both_h(tc.z, tr.z, td.z, tdr.z);
-    l.both[i] = uint4{as_u(bR), as_u(bG), as_u(bB), 0u};
-  }
-  __syncthreads();
-
-  const int lane = tid & 63, wave = tid >> 6;
   const int ox = ox0 + lane;
   if (ox >= a.out.width) return;
   char* const out_col = a.out.base + (long long)frame * a.out.frame_stride + (size_t)ox * sizeof(half4_t);
@@ -93,7 +182,6 @@ __global__ void __launch_bounds__(kThreads) easu_h_kernel(const EasuArgs a) {
   const float fpx = floorf(ppx);
   ppx -= fpx;
   const int lx = (int)fpx - fx0;
-  const bool hdr = (a.flags & FSR1_FLAG_HDR_SQUARE) != 0;
 
 #pragma unroll 1
   for (int r = 0; r < kTileH / 4; ++r) {
@@ -104,34 +192,22 @@ __global__ void __launch_bounds__(kThreads) easu_h_kernel(const EasuArgs a) {
     ppy -= fpy;
     const half2_t ppp = h2((half_t)ppx, (half_t)ppy);  // :516 AH2(pp), RTNE
     const int f = ((int)fpy - fy0) * fw + lx;            // footprint index of texel 'f'
-    // texP[t] holds (t, t+1), so the reference's pairs bc / ij / kl come as stored and fe / hg / on are the swapped
-    // (e,f) / (g,h) / (n,o)
-    const uint4 bo = l.both[f];
-    const rgbh_t px = easu_filter_h(
-        [&](int k) { return l.ana1[f + (k >> 1) * fw + (k & 1)]; },
-        [&](int i) {
-          const int at[6] = {f - fw, f + fw - 1, f - 1, f + fw + 1, f + 1, f + 2 * fw};
-          const uint4 t = l.texP[at[i]];
-          const bool sw = i == 2 || i == 4 || i == 5;
-          return sw ? EasuHPair{swap2(as_h2(t.x)), swap2(as_h2(t.y)), swap2(as_h2(t.z))} : EasuHPair{as_h2(t.x), as_h2(t.y), as_h2(t.z)};
-        },
-        [&](int c) { return as_h2(c == 0 ? bo.x : (c == 1 ? bo.y : bo.z)); }, ppp);
-    half_t pr = px.r, pg = px.g, pb = px.b;
-    if (hdr) { pr = pr * pr; pg = pg * pg; pb = pb * pb; }  // FSR_Pass.hlsl:78-79
-    *reinterpret_cast<half4_t*>(out_col + (long long)oy * a.out.pitch) = half4_t{pr, pg, pb, one};  // alpha = 1, FSR_Pass.hlsl:80
+    *reinterpret_cast<half4_t*>(out_col + (long long)oy * a.out.pitch) = easu_h_pixel(l, f, fw, ppp, hdr);
   }
 }
 
 size_t easu_h_lds_bytes(int fp_w, int fp_h) { return (size_t)fp_w * fp_h * 48; }
 
-hipError_t easu_h_launch(const EasuArgs& a, hipStream_t stream) {
+// s2: launch the exact-2x variant (the caller has checked con0 and laid the grid out for the shifted tiles).
+hipError_t easu_h_launch(const EasuArgs& a, bool s2, hipStream_t stream) {
   const dim3 grid((unsigned)(a.tiles_x * a.tiles_y * a.frames)), block(kThreads);
   const size_t lds = easu_h_lds_bytes(a.fp_w, a.fp_h);
-  if (lds > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&easu_h_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
+  if (s2) {
+    hipLaunchKernelGGL(easu_h_kernel<true>, grid, block, lds, stream, a);
+    return hipGetLastError();
   }
-  hipLaunchKernelGGL(easu_h_kernel, grid, block, lds, stream, a);
+  if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&easu_h_kernel<false>), lds); e != hipSuccess) return e;
+  hipLaunchKernelGGL(easu_h_kernel<false>, grid, block, lds, stream, a);
   return hipGetLastError();
 }
 

@@ -62,7 +62,11 @@ __device__ __forceinline__ void rcas_strip(const RcasArgs& a, int frame, int x0,
   auto load = [&](int y, row_t& r) {
     if (!INTERIOR) r.halo = Pixel<FMT>::zero();
     if (INTERIOR) {
+#ifdef FSR1_RCAS_NT_LOAD  // tuning experiment
+      const pair_t pr = __builtin_nontemporal_load(reinterpret_cast<const pair_t*>(in_col + (long long)y * a.in.pitch));
+#else
       const pair_t pr = *reinterpret_cast<const pair_t*>(in_col + (long long)y * a.in.pitch);
+#endif
       __builtin_memcpy(&r.p0, &pr, sizeof(texel_t));
       __builtin_memcpy(&r.p1, reinterpret_cast<const char*>(&pr) + sizeof(texel_t), sizeof(texel_t));
 #ifdef FSR1_RCAS_NO_HALO  // timing experiment only (wrong at strip edges)
@@ -148,7 +152,11 @@ __device__ __forceinline__ void rcas_strip(const RcasArgs& a, int frame, int x0,
           out_pair_t pr;
           __builtin_memcpy(&pr, &t0, sizeof(out_t));
           __builtin_memcpy(reinterpret_cast<char*>(&pr) + sizeof(out_t), &t1, sizeof(out_t));
+#ifdef FSR1_RCAS_NT_STORE  // tuning experiment: the final image is not read again by this pipeline
+          __builtin_nontemporal_store(pr, reinterpret_cast<out_pair_t*>(dst));
+#else
           *reinterpret_cast<out_pair_t*>(dst) = pr;
+#endif
         } else if (ok0) {
           *reinterpret_cast<out_t*>(dst) = t0;
         }

@@ -155,3 +155,22 @@ def test_h_vs_f_distance_is_reported(fsr, port, record_property):
     record_property("easu_h_max_ulp_from_f", int(d.max()))
     print("EASU H vs F oracle: %.1f %% of values within 1 binary16 ULP, max %d ULP" % (100 * within1, d.max()))
     assert within1 > 0.25  # sanity only: it is the same filter
+
+
+@pytest.mark.parametrize("shape", [(480, 270, 960, 540), (37, 23, 74, 46), (1, 1, 2, 2), (33, 9, 66, 18), (64, 16, 128, 32)],
+                         ids=lambda s: "%dx%d_to_%dx%d" % s)
+def test_easu_h_exact_2x_variant_is_bit_identical(fsr, port, shape):
+    """At exactly 2x the H kernel whose lanes own 2x2 output quads (shifted tiles, compile-time footprint and sub-texel
+    positions) must reproduce the generic H kernel bit for bit — and both the CPU-evaluated FsrEasuH."""
+    iw, ih, ow, oh = shape
+    img = frames.synthetic_frame(iw, ih, k=9, dtype=np.float16)
+    src = dev(img)
+    fast = torch.zeros(oh, ow, 4, dtype=torch.float16, device="cuda")
+    slow = torch.zeros_like(fast)
+    for hdr in (0, fsr.FLAG_HDR_SQUARE):
+        fsr.easu(src, fast, flags=fsr.FLAG_MATH_PACKED_FP16 | hdr)
+        fsr.easu(src, slow, flags=fsr.FLAG_MATH_PACKED_FP16 | fsr.FLAG_NO_FAST_PATHS | hdr)
+        assert torch.equal(fast.view(torch.int16), slow.view(torch.int16)), "H exact-2x variant differs from the generic H kernel (hdr %d)" % hdr
+    con = port.FsrEasuCon(iw, ih, iw, ih, ow, oh)
+    fsr.easu(src, fast, con=con, flags=fsr.FLAG_MATH_PACKED_FP16)
+    assert_bits16(host(fast), port.easu_h(img.astype(np.float32), ow, oh, con), "easu H exact-2x vs oracle")
