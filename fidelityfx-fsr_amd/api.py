@@ -25,6 +25,8 @@ FLAG_RCAS_PASSTHROUGH_ALPHA = 1 << 2
 FLAG_MATH_EXACT = 1 << 4
 FLAG_MATH_PACKED_FP16 = 1 << 5
 FLAG_NO_FAST_PATHS = 1 << 8
+FLAG_OUTPUT_STREAMING = 1 << 9
+FLAG_OUTPUT_CACHED = 1 << 10
 
 # colour stages (ffx_fsr1.h:986-1199), fixed order SRTM -> LFGA -> SRTM_INV -> TEPD
 COLOR_SRTM = 1 << 0

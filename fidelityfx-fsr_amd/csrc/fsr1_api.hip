@@ -120,13 +120,22 @@ static int check_grid(const char* who, int tiles_x, int tiles_y, int frames) {
 }
 
 static const uint32_t kKnownFlags = FSR1_FLAG_HDR_SQUARE | FSR1_FLAG_RCAS_DENOISE | FSR1_FLAG_RCAS_PASSTHROUGH_ALPHA |
-                                    FSR1_FLAG_MATH_EXACT | FSR1_FLAG_MATH_PACKED_FP16 | FSR1_FLAG_NO_FAST_PATHS;
+                                    FSR1_FLAG_MATH_EXACT | FSR1_FLAG_MATH_PACKED_FP16 | FSR1_FLAG_NO_FAST_PATHS |
+                                    FSR1_FLAG_OUTPUT_STREAMING | FSR1_FLAG_OUTPUT_CACHED;
 
 static int check_flags(uint32_t flags) {
   if (flags & ~kKnownFlags) return fail(FSR1_ERR_INVALID_ARGUMENT, "unknown flag bits 0x%x", flags & ~kKnownFlags);
   if ((flags & FSR1_FLAG_MATH_EXACT) && (flags & FSR1_FLAG_MATH_PACKED_FP16))
     return fail(FSR1_ERR_INVALID_ARGUMENT, "FSR1_FLAG_MATH_EXACT and FSR1_FLAG_MATH_PACKED_FP16 are exclusive");
+  if ((flags & FSR1_FLAG_OUTPUT_STREAMING) && (flags & FSR1_FLAG_OUTPUT_CACHED))
+    return fail(FSR1_ERR_INVALID_ARGUMENT, "FSR1_FLAG_OUTPUT_STREAMING and FSR1_FLAG_OUTPUT_CACHED are exclusive");
   return FSR1_OK;
+}
+
+// The store policy the kernels see: exactly one of the two bits, resolved against the pass's default.
+static uint32_t resolve_output_policy(uint32_t flags, bool streaming_by_default) {
+  const bool streaming = (flags & FSR1_FLAG_OUTPUT_STREAMING) || (streaming_by_default && !(flags & FSR1_FLAG_OUTPUT_CACHED));
+  return (flags & ~(uint32_t)(FSR1_FLAG_OUTPUT_STREAMING | FSR1_FLAG_OUTPUT_CACHED)) | (streaming ? FSR1_FLAG_OUTPUT_STREAMING : 0u);
 }
 
 // fsr1_color_stages -> the device-side ColorArgs; `allowed` = the stage bits this entry point can run.
@@ -217,7 +226,7 @@ int fsr1_easu_dispatch_ex(const fsr1_image* in, const fsr1_image* out, const uin
   a.tiles_x = (out->width + kTileW - 1) / kTileW;
   a.tiles_y = (out->height + kTileH - 1) / kTileH;
   a.frames = out->frames;
-  a.flags = flags;
+  a.flags = resolve_output_policy(flags, false);  // RCAS normally follows: keep the intermediary cached
   // Exact 2x with the viewport covering the input — con0 = {1/2, 1/2, -1/4, -1/4}, what FsrEasuCon gives for
   // out = 2 * in — takes the variant whose lanes own 2x2 output quads; its tiles are shifted by one pixel, hence one
   // more tile per axis when the size is a multiple of the tile, and the footprint of a tile is 64/2+3 x 16/2+3 texels.
@@ -267,7 +276,7 @@ int fsr1_rcas_dispatch_ex(const fsr1_image* in, const fsr1_image* out, const uin
   rcas_geometry(out->width, out->height, out->frames, &a.tiles_x, &a.tiles_y, &a.rows);
   a.frames = out->frames;
   if ((rc = check_grid("rcas", a.tiles_x, a.tiles_y, a.frames))) return rc;
-  a.flags = flags;
+  a.flags = resolve_output_policy(flags, true);
   hipError_t e;
   if (flags & FSR1_FLAG_MATH_PACKED_FP16) {
     if (in->format != FSR1_FORMAT_RGBA16F) return fail(FSR1_ERR_UNSUPPORTED, "rcas: packed-fp16 math needs RGBA16F images");
@@ -319,7 +328,7 @@ int fsr1_easu_rcas_fused_dispatch_ex(const fsr1_image* in, const fsr1_image* out
   a.tiles_y = (out->height + kFusedTileH - 1) / kFusedTileH;
   a.frames = out->frames;
   if ((rc = check_grid("fused", a.tiles_x, a.tiles_y, a.frames))) return rc;
-  a.flags = flags;
+  a.flags = resolve_output_policy(flags, true);
   const bool exact = (flags & FSR1_FLAG_MATH_EXACT) != 0;
   hipError_t e = a.color.stages ? fused_color_launch(a, in->format, out->format, exact, static_cast<hipStream_t>(stream))
                                 : fused_launch(a, in->format, exact, static_cast<hipStream_t>(stream));
@@ -377,14 +386,16 @@ int fsr1_upscale_ex(const fsr1_image* in, const fsr1_image* intermediary, const 
              p->render_height, (float)out->width, (float)out->height);
   const uint32_t math = p->flags & (FSR1_FLAG_MATH_EXACT | FSR1_FLAG_MATH_PACKED_FP16 | FSR1_FLAG_NO_FAST_PATHS);
   const uint32_t rcas_opts = p->flags & (FSR1_FLAG_RCAS_DENOISE | FSR1_FLAG_RCAS_PASSTHROUGH_ALPHA);
-  if (p->flags & ~(math | rcas_opts)) return fail(FSR1_ERR_INVALID_ARGUMENT, "upscale: params.flags may only hold MATH_* and RCAS_* bits");
+  const uint32_t out_policy = p->flags & (FSR1_FLAG_OUTPUT_STREAMING | FSR1_FLAG_OUTPUT_CACHED);  // of the pass that writes `out`
+  if (p->flags & ~(math | rcas_opts | out_policy)) return fail(FSR1_ERR_INVALID_ARGUMENT, "upscale: params.flags may only hold MATH_*, RCAS_* and OUTPUT_* bits");
   if (stages && !stages->stages) stages = nullptr;
   if (!p->use_rcas) {
     // :107 Sample.x = hdr && !bUseRcas ; :140 EASU straight into the output
-    return fsr1_easu_dispatch_ex(in, out, easu_con, math | (p->hdr ? FSR1_FLAG_HDR_SQUARE : 0u), stages, stream);
+    return fsr1_easu_dispatch_ex(in, out, easu_con, math | (p->hdr ? FSR1_FLAG_HDR_SQUARE : 0u) | (out_policy ? out_policy : (uint32_t)FSR1_FLAG_OUTPUT_STREAMING),
+                                 stages, stream);
   }
   FsrRcasCon(rcas_con, p->rcas_attenuation);  // :124
-  const uint32_t rcas_flags = math | rcas_opts | (p->hdr ? FSR1_FLAG_HDR_SQUARE : 0u);  // :125 Sample.x = hdr
+  const uint32_t rcas_flags = math | rcas_opts | out_policy | (p->hdr ? FSR1_FLAG_HDR_SQUARE : 0u);  // :125 Sample.x = hdr
   bool fused = p->fused == 1;
   if (p->fused == 2) {  // auto: the fused kernel's apron and LDS footprint grow as the scale shrinks
     float sx, sy;

@@ -132,6 +132,7 @@ __global__ void __launch_bounds__(kThreads) easu_h_kernel(const EasuArgs a) {
   const int lane = tid & 63, wave = tid >> 6;
   const char* const in_frame = a.in.base + (long long)frame * a.in.frame_stride;
   const bool hdr = (a.flags & FSR1_FLAG_HDR_SQUARE) != 0;
+  const bool stream = (a.flags & FSR1_FLAG_OUTPUT_STREAMING) != 0;
 
   if constexpr (S2) {
     static_assert(kTileW == 64 && kTileH == 16, "the exact-2x variant is built for 64 x 16 tiles");
@@ -145,21 +146,18 @@ __global__ void __launch_bounds__(kThreads) easu_h_kernel(const EasuArgs a) {
     const int f = (qy + 1) * kS2W + (qx + 1);
     char* const o0 = a.out.base + (long long)frame * a.out.frame_stride + (long long)oya * a.out.pitch + (long long)oxa * 8;
     const half_t q1 = (half_t)0.25f, q3 = (half_t)0.75f;
-    struct __attribute__((aligned(8))) pair_t { half4_t p[2]; };
+    typedef TexelPair<FSR1_FORMAT_RGBA16F> pair;
     if (xin0 && xin1 && yin0 && yin1) {
-      pair_t r0, r1;
-      r0.p[0] = easu_h_pixel(l, f, kS2W, h2(q1, q1), hdr);
-      r0.p[1] = easu_h_pixel(l, f, kS2W, h2(q3, q1), hdr);
-      r1.p[0] = easu_h_pixel(l, f, kS2W, h2(q1, q3), hdr);
-      r1.p[1] = easu_h_pixel(l, f, kS2W, h2(q3, q3), hdr);
-      *reinterpret_cast<pair_t*>(o0) = r0;
-      *reinterpret_cast<pair_t*>(o0 + a.out.pitch) = r1;
+      const half4_t p00 = easu_h_pixel(l, f, kS2W, h2(q1, q1), hdr), p10 = easu_h_pixel(l, f, kS2W, h2(q3, q1), hdr);
+      const half4_t p01 = easu_h_pixel(l, f, kS2W, h2(q1, q3), hdr), p11 = easu_h_pixel(l, f, kS2W, h2(q3, q3), hdr);
+      store_out<8>(o0, pair::make(p00, p10), stream);
+      store_out<8>(o0 + a.out.pitch, pair::make(p01, p11), stream);
       return;
     }
     auto row = [&](char* o, bool yin, half_t ppy) {
       if (!yin) return;
-      if (xin0) *reinterpret_cast<half4_t*>(o) = easu_h_pixel(l, f, kS2W, h2(q1, ppy), hdr);
-      if (xin1) *reinterpret_cast<half4_t*>(o + 8) = easu_h_pixel(l, f, kS2W, h2(q3, ppy), hdr);
+      if (xin0) store_out<8>(o, easu_h_pixel(l, f, kS2W, h2(q1, ppy), hdr), stream);
+      if (xin1) store_out<8>(o + 8, easu_h_pixel(l, f, kS2W, h2(q3, ppy), hdr), stream);
     };
     row(o0, yin0, q1);
     row(o0 + a.out.pitch, yin1, q3);
@@ -192,7 +190,7 @@ __global__ void __launch_bounds__(kThreads) easu_h_kernel(const EasuArgs a) {
     ppy -= fpy;
     const half2_t ppp = h2((half_t)ppx, (half_t)ppy);  // :516 AH2(pp), RTNE
     const int f = ((int)fpy - fy0) * fw + lx;            // footprint index of texel 'f'
-    *reinterpret_cast<half4_t*>(out_col + (long long)oy * a.out.pitch) = easu_h_pixel(l, f, fw, ppp, hdr);
+    store_out<8>(out_col + (long long)oy * a.out.pitch, easu_h_pixel(l, f, fw, ppp, hdr), stream);
   }
 }
 

@@ -46,7 +46,7 @@ __global__ void __launch_bounds__(kThreads) easu_kernel(const EasuArgs a) {
     easu_stage_footprint<FMT, false, EXACT, kS2W, kS2H>(l, a.in, in_frame, fx0, fy0, kS2W, kS2H, tid);
     const int W = a.out.width, H = a.out.height;
     constexpr bool hdr = HDR;
-    struct __attribute__((aligned(sizeof(texel_t)))) pair_t { texel_t p[2]; };
+    const bool stream = (a.flags & FSR1_FLAG_OUTPUT_STREAMING) != 0;
 #pragma unroll 1
     for (int k = 0; k < kTileH / 16; ++k) {
       const int qx = lane & 31, qy = (kTileH / 8) * wave + 2 * k + (lane >> 5);
@@ -58,19 +58,18 @@ __global__ void __launch_bounds__(kThreads) easu_kernel(const EasuArgs a) {
       const EasuBounds m = easu_bounds(l, f_idx);  // one 2x2 block for the whole quad
       if (xin0 && xin1 && yin0 && yin1) {
         // the whole quad lies inside the image (every lane of every tile but those on the image's border): no predicates
-        pair_t r0, r1;
-        r0.p[0] = easu_resolve<FMT, EXACT>(m, easu_pixel<EXACT>(l, f_idx, 0.25f, 0.25f), hdr);
-        r0.p[1] = easu_resolve<FMT, EXACT>(m, easu_pixel<EXACT>(l, f_idx, 0.75f, 0.25f), hdr);
-        r1.p[0] = easu_resolve<FMT, EXACT>(m, easu_pixel<EXACT>(l, f_idx, 0.25f, 0.75f), hdr);
-        r1.p[1] = easu_resolve<FMT, EXACT>(m, easu_pixel<EXACT>(l, f_idx, 0.75f, 0.75f), hdr);
-        *reinterpret_cast<pair_t*>(o0) = r0;
-        *reinterpret_cast<pair_t*>(o0 + a.out.pitch) = r1;
+        const texel_t p00 = easu_resolve<FMT, EXACT>(m, easu_pixel<EXACT>(l, f_idx, 0.25f, 0.25f), hdr);
+        const texel_t p10 = easu_resolve<FMT, EXACT>(m, easu_pixel<EXACT>(l, f_idx, 0.75f, 0.25f), hdr);
+        const texel_t p01 = easu_resolve<FMT, EXACT>(m, easu_pixel<EXACT>(l, f_idx, 0.25f, 0.75f), hdr);
+        const texel_t p11 = easu_resolve<FMT, EXACT>(m, easu_pixel<EXACT>(l, f_idx, 0.75f, 0.75f), hdr);
+        store_out<sizeof(texel_t)>(o0, TexelPair<FOUT>::make(p00, p10), stream);
+        store_out<sizeof(texel_t)>(o0 + a.out.pitch, TexelPair<FOUT>::make(p01, p11), stream);
         continue;
       }
       auto row = [&](char* o, bool yin, float ppy) {
         if (!yin) return;
-        if (xin0) *reinterpret_cast<texel_t*>(o) = easu_resolve<FMT, EXACT>(m, easu_pixel<EXACT>(l, f_idx, 0.25f, ppy), hdr);
-        if (xin1) *reinterpret_cast<texel_t*>(o + sizeof(texel_t)) = easu_resolve<FMT, EXACT>(m, easu_pixel<EXACT>(l, f_idx, 0.75f, ppy), hdr);
+        if (xin0) store_out<sizeof(texel_t)>(o, easu_resolve<FMT, EXACT>(m, easu_pixel<EXACT>(l, f_idx, 0.25f, ppy), hdr), stream);
+        if (xin1) store_out<sizeof(texel_t)>(o + sizeof(texel_t), easu_resolve<FMT, EXACT>(m, easu_pixel<EXACT>(l, f_idx, 0.75f, ppy), hdr), stream);
       };
       row(o0, yin0, 0.25f);
       row(o0 + a.out.pitch, yin1, 0.75f);
@@ -102,6 +101,7 @@ __global__ void __launch_bounds__(kThreads) easu_kernel(const EasuArgs a) {
   // `c *= c` (FSR_Pass.hlsl:78-79) is a template parameter of the plain kernels (a run-time flag costs three multiplies
   // and three selects per pixel for an option only the EASU-only HDR path uses); the colour variants read the flag
   const bool hdr = COLOR ? (a.flags & FSR1_FLAG_HDR_SQUARE) != 0 : HDR;
+  const bool stream = (a.flags & FSR1_FLAG_OUTPUT_STREAMING) != 0;
 
 #pragma unroll 1
   for (int r = 0; r < kTileH / 4; ++r) {
@@ -117,9 +117,9 @@ __global__ void __launch_bounds__(kThreads) easu_kernel(const EasuArgs a) {
     if constexpr (COLOR) {
       rgbf_t q = easu_clamp<EXACT>(m, p, hdr);
       color_epilogue<EXACT>(a.color, (uint32_t)ox, (uint32_t)oy, q.r, q.g, q.b);
-      *dst = Pixel<FOUT>::store(q.r, q.g, q.b, 1.0f);
+      store_out<sizeof(texel_t)>(dst, Pixel<FOUT>::store(q.r, q.g, q.b, 1.0f), stream);
     } else {
-      *dst = easu_resolve<FMT, EXACT>(m, p, hdr);
+      store_out<sizeof(texel_t)>(dst, easu_resolve<FMT, EXACT>(m, p, hdr), stream);
     }
   }
 }

@@ -95,6 +95,7 @@ __global__ void __launch_bounds__(kThreads) fused_kernel(const FusedArgs a) {
   const int ox = ox0 + lane;
   const float sharp = as_f32(a.rcas_con[0]);
   const uint32_t flags = a.flags;
+  const bool stream = (flags & FSR1_FLAG_OUTPUT_STREAMING) != 0;
   char* const out_col = a.out.base + (long long)frame * a.out.frame_stride + (size_t)ox * sizeof(out_t);
   auto rgb = [](const texel_t& p) { const float4_t c = Pixel<FMT>::load(p); return rgb_t{c.x, c.y, c.z}; };
   constexpr int kRowsPerWave = kFusedTileH / 4;
@@ -115,7 +116,7 @@ __global__ void __launch_bounds__(kThreads) fused_kernel(const FusedArgs a) {
     if (ox < W && oy < H) {
       const float pa = (flags & FSR1_FLAG_RCAS_PASSTHROUGH_ALPHA) ? Pixel<FMT>::load(e_raw).w : 1.0f;
       if constexpr (COLOR) color_epilogue<EXACT>(a.color, (uint32_t)ox, (uint32_t)oy, p.r, p.g, p.b);
-      *reinterpret_cast<out_t*>(out_col + (long long)oy * a.out.pitch) = Pixel<FOUT>::store(p.r, p.g, p.b, pa);
+      store_out<sizeof(out_t)>(out_col + (long long)oy * a.out.pitch, Pixel<FOUT>::store(p.r, p.g, p.b, pa), stream);
     }
     prev = cur; cur = next; e_raw = n_raw;
   }

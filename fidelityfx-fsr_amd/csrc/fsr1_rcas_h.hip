@@ -32,6 +32,7 @@ __device__ __forceinline__ half2_t dpp2(half2_t keep, half2_t v) {
 template <bool OPTS>
 __global__ void __launch_bounds__(kThreads) rcas_h_kernel(const RcasArgs a) {
   const uint32_t flags = OPTS ? a.flags : 0u;
+  const bool stream = (a.flags & FSR1_FLAG_OUTPUT_STREAMING) != 0;
   const int tiles_per_frame = a.tiles_x * a.tiles_y;
   const int t = xcd_swizzle(blockIdx.x, tiles_per_frame * a.frames);
   const int frame = t / tiles_per_frame;
@@ -96,8 +97,9 @@ __global__ void __launch_bounds__(kThreads) rcas_h_kernel(const RcasArgs a) {
     if (y < H) {
       char* const row = out_frame + (long long)y * a.out.pitch;
       // FsrRcasDepackHx2 :880-886
-      if (ok0) *reinterpret_cast<half4_t*>(row + (size_t)col * 8) = half4_t{pR.x, pG.x, pB.x, pA.x};
-      if (ok1) *reinterpret_cast<half4_t*>(row + (size_t)(col + 1) * 8) = half4_t{pR.y, pG.y, pB.y, pA.y};
+      const half4_t t0 = {pR.x, pG.x, pB.x, pA.x}, t1 = {pR.y, pG.y, pB.y, pA.y};
+      if (ok1) store_out<8>(row + (size_t)col * 8, TexelPair<FSR1_FORMAT_RGBA16F>::make(t0, t1), stream);
+      else if (ok0) store_out<8>(row + (size_t)col * 8, t0, stream);
     }
     prev = e;
   }

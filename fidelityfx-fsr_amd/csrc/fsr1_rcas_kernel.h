@@ -44,6 +44,7 @@ __device__ __forceinline__ void rcas_strip(const RcasArgs& a, int frame, int x0,
   typedef typename Pixel<FOUT>::T out_t;
   typedef typename RcasPair<FOUT>::T out_pair_t;
   const uint32_t flags = OPTS ? a.flags : 0u;
+  const bool stream = (a.flags & FSR1_FLAG_OUTPUT_STREAMING) != 0;
   const int W = a.in.width, H = a.in.height;
   const int col = x0 + 2 * lane;
   const bool ok0 = INTERIOR || col < W, ok1 = INTERIOR || col + 1 < W;
@@ -152,13 +153,9 @@ __device__ __forceinline__ void rcas_strip(const RcasArgs& a, int frame, int x0,
           out_pair_t pr;
           __builtin_memcpy(&pr, &t0, sizeof(out_t));
           __builtin_memcpy(reinterpret_cast<char*>(&pr) + sizeof(out_t), &t1, sizeof(out_t));
-#ifdef FSR1_RCAS_NT_STORE  // tuning experiment: the final image is not read again by this pipeline
-          __builtin_nontemporal_store(pr, reinterpret_cast<out_pair_t*>(dst));
-#else
-          *reinterpret_cast<out_pair_t*>(dst) = pr;
-#endif
+          store_out<sizeof(out_t)>(dst, pr, stream);
         } else if (ok0) {
-          *reinterpret_cast<out_t*>(dst) = t0;
+          store_out<sizeof(out_t)>(dst, t0, stream);
         }
       }
       prev0 = cur0; prev1 = cur1; cur0 = next0; cur1 = next1;

@@ -58,6 +58,23 @@ __device__ __forceinline__ float mad(float a, float b, float c) { return EXACT ?
 // takes 55.0 us instead of 48.7 us (capped at 64 VGPRs it spills: 87 us).  LDS bandwidth is not what EASU is short of.
 __device__ __forceinline__ float pinned(float x) { asm volatile("" : "+v"(x)); return x; }
 
+// Store of a pass's output: non-temporal when the image is the pipeline's last (FSR1_FLAG_OUTPUT_STREAMING), plain when a
+// reader follows.  `streaming` is wave-uniform (a kernel argument), so this is a scalar branch around one store.
+// ALIGN: what the address is known to be aligned to (a pair of texels is only texel-aligned).
+template <int ALIGN, class T>
+__device__ __forceinline__ void store_out(void* p, T v, bool streaming) {
+  typedef T aligned_t __attribute__((aligned(ALIGN)));
+  if (streaming) {
+    // The empty statements keep this store distinct for the optimiser: it otherwise hoists / sinks the two branches'
+    // stores into one and, intersecting their metadata, drops the non-temporal hint.  They emit nothing.
+    asm volatile("");
+    __builtin_nontemporal_store(v, reinterpret_cast<aligned_t*>(p));
+    asm volatile("");
+  } else {
+    *reinterpret_cast<aligned_t*>(p) = v;
+  }
+}
+
 // RTNE float -> binary16 (v_cvt_f16_f32 under the default rounding mode; never cvt_pkrtz).
 __device__ __forceinline__ half_t to_half(float f) { return (half_t)f; }
 
@@ -113,6 +130,25 @@ template <> struct Pixel<FSR1_FORMAT_RGBA32F> {
   static __device__ __forceinline__ float4_t load(const T& p) { return p; }
   static __device__ __forceinline__ T store(float r, float g, float b, float a) { return T{r, g, b, a}; }
   static __device__ __forceinline__ T zero() { return T{0.f, 0.f, 0.f, 0.f}; }
+};
+
+// Two horizontally adjacent texels as ONE value, so that a lane owning both moves them with a single access.
+template <int FMT> struct TexelPair;
+template <> struct TexelPair<FSR1_FORMAT_RGBA16F> {
+  typedef half_t T __attribute__((ext_vector_type(8), aligned(8)));
+  static __device__ __forceinline__ T make(half4_t a, half4_t b) { return T{a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w}; }
+};
+template <> struct TexelPair<FSR1_FORMAT_RGBA32F> {
+  typedef float T __attribute__((ext_vector_type(8), aligned(16)));
+  static __device__ __forceinline__ T make(float4_t a, float4_t b) { return T{a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w}; }
+};
+template <> struct TexelPair<FSR1_FORMAT_RGBA8_UNORM> {
+  typedef uint32_t T __attribute__((ext_vector_type(2), aligned(4)));
+  static __device__ __forceinline__ T make(uint32_t a, uint32_t b) { return T{a, b}; }
+};
+template <> struct TexelPair<FSR1_FORMAT_R10G10B10A2_UNORM> {
+  typedef uint32_t T __attribute__((ext_vector_type(2), aligned(4)));
+  static __device__ __forceinline__ T make(uint32_t a, uint32_t b) { return T{a, b}; }
 };
 
 }  // namespace fsr1

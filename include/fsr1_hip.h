@@ -97,7 +97,14 @@ enum {
   /* Diagnostics: never pick a shape-specialised kernel (e.g. the exact-2x variants, whose lanes own 2x2 output quads).
    * The specialised kernels run the same per-pixel arithmetic on the same values: results are bit-identical either way
    * (tests assert it); the flag exists so that this can be checked and the gain measured. */
-  FSR1_FLAG_NO_FAST_PATHS = 1u << 8
+  FSR1_FLAG_NO_FAST_PATHS = 1u << 8,
+  /* Store policy of the pass's output image.  STREAMING: non-temporal stores — the image is not read again soon, so it
+   * should not displace what is (measured on MI355X at 4K: RCAS 30.9 -> 25.7 us, two dispatches 70.2 -> 67.5 us).
+   * CACHED: plain stores — a reader follows (the EASU -> RCAS intermediary).  Defaults: EASU CACHED (RCAS normally
+   * follows), RCAS and the fused launch STREAMING (their output is the pipeline's last image); fsr1_upscale sets
+   * STREAMING on whichever pass writes `out`.  The pixels stored are the same either way. */
+  FSR1_FLAG_OUTPUT_STREAMING = 1u << 9,
+  FSR1_FLAG_OUTPUT_CACHED = 1u << 10
 };
 
 typedef enum fsr1_status {

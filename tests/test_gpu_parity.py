@@ -528,3 +528,26 @@ def test_random_shapes_sweep(fsr, port):
                 assert cpu_oracle.half_ulp_diff(got_out.astype(np.float32), want_out).max() <= 1, what + " rcas"
             cases += 1
     assert cases == 96
+
+
+def test_output_store_policy_does_not_change_pixels(fsr):
+    """FSR1_FLAG_OUTPUT_STREAMING (non-temporal stores; the default of RCAS and the fused launch) and
+    FSR1_FLAG_OUTPUT_CACHED (plain stores; EASU's default) store the very same image, for every pass and both shapes."""
+    for (iw, ih, ow, oh) in ((160, 90, 320, 180), (97, 61, 131, 83)):
+        src = dev(frames.synthetic_frame(iw, ih, k=12, dtype=np.float16))
+        outs = []
+        for policy in (fsr.FLAG_OUTPUT_CACHED, fsr.FLAG_OUTPUT_STREAMING, 0):
+            mid = torch.zeros(oh, ow, 4, dtype=torch.float16, device="cuda")
+            out = torch.zeros_like(mid)
+            fus = torch.zeros_like(mid)
+            fsr.easu(src, mid, flags=policy)
+            fsr.rcas(mid, out, flags=policy)
+            fsr.easu_rcas_fused(src, fus, flags=policy)
+            hmid = torch.zeros_like(mid)
+            hout = torch.zeros_like(mid)
+            fsr.easu(src, hmid, flags=policy | fsr.FLAG_MATH_PACKED_FP16)
+            fsr.rcas(hmid, hout, flags=policy | fsr.FLAG_MATH_PACKED_FP16)
+            outs.append((mid, out, fus, hmid, hout))
+        for other in outs[1:]:
+            for a, b in zip(outs[0], other):
+                assert torch.equal(a.view(torch.int16), b.view(torch.int16))

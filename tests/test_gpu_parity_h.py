@@ -174,3 +174,22 @@ def test_easu_h_exact_2x_variant_is_bit_identical(fsr, port, shape):
     con = port.FsrEasuCon(iw, ih, iw, ih, ow, oh)
     fsr.easu(src, fast, con=con, flags=fsr.FLAG_MATH_PACKED_FP16)
     assert_bits16(host(fast), port.easu_h(img.astype(np.float32), ow, oh, con), "easu H exact-2x vs oracle")
+
+
+def test_upscale_auto_with_packed_fp16(fsr, port):
+    """FSR_Filter.OnCreate(slowFallback=False, fused="auto") — the reference's default permutation with the pipeline left
+    to the library — at exactly 2x: the packed-fp16 entry points exist as two dispatches only, so `auto` must take them
+    (round 1 routed this to the fused launch, which rejects packed-fp16)."""
+    iw, ih, ow, oh = 160, 90, 320, 180
+    img = frames.synthetic_frame(iw, ih, k=6, dtype=np.float16)
+    src = dev(img)
+    dst = torch.zeros(oh, ow, 4, dtype=torch.float16, device="cuda")
+    filt = fsr.FSR_Filter()
+    filt.OnCreate(slowFallback=False, fused="auto")
+    filt.OnCreateWindowSizeDependentResources(src, dst, ow, oh)
+    filt.Upscale(ow, oh, fsr.State(iw, ih, bUseRcas=True, rcasAttenuation=0.25))
+    con = port.FsrEasuCon(iw, ih, iw, ih, ow, oh)
+    mid = host(filt.m_intermediary).reshape(oh, ow, 4)
+    assert_bits16(mid, port.easu_h(img.astype(np.float32), ow, oh, con), "auto + packed fp16: easu")
+    assert_bits16(host(dst), port.rcas_h(mid.astype(np.float32), port.FsrRcasCon(0.25)), "auto + packed fp16: rcas")
+    filt.OnDestroy()
