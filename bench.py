@@ -223,8 +223,8 @@ def main():
             fsr.easu_rcas_fused(srcs[s], dsts[s], easu_con=easu_con, rcas_con=rcas_con, flags=math_flags, stages=stages)
         elif args.pipeline == "color":
             fsr.color(srcs[s], dsts[s], stages, flags=math_flags)
-        else:
-            fsr.easu(srcs[s], dsts[s], con=easu_con, flags=math_flags, stages=stages)
+        else:  # EASU only: its output is the pipeline's last image (what fsr1_upscale does with use_rcas = 0)
+            fsr.easu(srcs[s], dsts[s], con=easu_con, flags=math_flags | fsr.FLAG_OUTPUT_STREAMING, stages=stages)
 
     def fence():
         torch.cuda.synchronize()
@@ -324,7 +324,8 @@ def main():
     kern = {}
     if args.pipeline in ("two-pass", "easu"):
         tgt = mids if args.pipeline == "two-pass" else dsts
-        kern["easu"] = kernel_ms(lambda i: fsr.easu(srcs[i % ring], tgt[i % ring], con=easu_con, flags=math_flags,
+        eflags = math_flags | (0 if args.pipeline == "two-pass" else fsr.FLAG_OUTPUT_STREAMING)
+        kern["easu"] = kernel_ms(lambda i: fsr.easu(srcs[i % ring], tgt[i % ring], con=easu_con, flags=eflags,
                                                     stages=pre if args.pipeline == "two-pass" else stages), n_k)
     if args.pipeline == "two-pass":
         kern["rcas"] = kernel_ms(lambda i: fsr.rcas(mids[i % ring], dsts[i % ring], con=rcas_con, flags=math_flags, stages=post), n_k)

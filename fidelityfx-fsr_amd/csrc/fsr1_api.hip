@@ -397,11 +397,9 @@ int fsr1_upscale_ex(const fsr1_image* in, const fsr1_image* intermediary, const 
   FsrRcasCon(rcas_con, p->rcas_attenuation);  // :124
   const uint32_t rcas_flags = math | rcas_opts | out_policy | (p->hdr ? FSR1_FLAG_HDR_SQUARE : 0u);  // :125 Sample.x = hdr
   bool fused = p->fused == 1;
-  if (p->fused == 2) {  // auto: the fused kernel's apron and LDS footprint grow as the scale shrinks
-    float sx, sy;
-    memcpy(&sx, &easu_con[0], 4);
-    memcpy(&sy, &easu_con[1], 4);
-    fused = !intermediary || (sx <= 0.55f && sy <= 0.55f);
+  if (p->fused == 2) {  // auto, on round-2 measurements: the fused launch pays off only where a frame is launch-bound
+    const long long out_pixels = (long long)out->width * (long long)out->height * (long long)out->frames;
+    fused = !intermediary || out_pixels <= 3000000ll;
     if (math & FSR1_FLAG_MATH_PACKED_FP16) {  // FsrEasuH / FsrRcasH exist as two dispatches only
       if (!intermediary) return fail(FSR1_ERR_INVALID_ARGUMENT, "upscale: packed-fp16 math runs as two dispatches and needs an intermediary image");
       fused = false;

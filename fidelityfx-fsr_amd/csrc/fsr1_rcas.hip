@@ -44,7 +44,11 @@ hipError_t rcas_launch(const RcasArgs& a, int fmt, bool exact, hipStream_t strea
   const dim3 grid((unsigned)(a.tiles_x * a.tiles_y * a.frames)), block(kRcasThreads);
   const bool opts = (a.flags & (FSR1_FLAG_RCAS_DENOISE | FSR1_FLAG_RCAS_PASSTHROUGH_ALPHA | FSR1_FLAG_HDR_SQUARE)) != 0;
   // shallow ring when the image is short of waves: fewer than 6 per SIMD in 16-row strips (RGBA32F: always 4 rows)
+#ifdef FSR1_RCAS_FORCE_SHALLOW  // tuning experiment
+  const bool shallow = true; (void)kRcasRing;
+#else
   const bool shallow = (long long)a.tiles_x * ((a.in.height + 15) / 16) * a.frames * kRcasWaves < 6LL * 4 * 256;
+#endif
 #define FSR1_RCAS(F, E, O)                                                                                                                  \
   do {                                                                                                                                      \
     if (shallow) hipLaunchKernelGGL((rcas_kernel<F, E, O, false, F, (F == FSR1_FORMAT_RGBA32F ? 4 : FSR1_RCAS_SHALLOW_RING)>), grid, block, 0, stream, a);       \

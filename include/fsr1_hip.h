@@ -209,11 +209,12 @@ typedef struct fsr1_params {
   float rcas_attenuation;              /* pState->rcasAttenuation, stops (sample default 0.25, SampleRenderer.h:49) */
   int32_t hdr;                         /* `hdr` argument of Upscale: Sample.x = hdr && !use_rcas for EASU, hdr for RCAS */
   int32_t fused;                       /* 0: EASU + RCAS as two dispatches; 1: the single fused launch (needs use_rcas);
-                                          2: whichever is faster on MI355X for this scale — the fused launch from about
-                                          1.8x per axis upwards (measured: 2.0x 74.6 vs 75.6 us, 1.7x 85.1 vs 83.3,
-                                          1.5x 102.8 vs 90.5, 1.3x 144 vs 101 at 4K output), two dispatches below; with
-                                          intermediary == NULL it is always the fused launch */
-  uint32_t flags;                      /* FSR1_FLAG_MATH_* and FSR1_FLAG_RCAS_DENOISE / _PASSTHROUGH_ALPHA */
+                                          2: whichever is faster on MI355X, decided on round-2 measurements: the two
+                                          dispatches whenever the launch has more than 3 Mpixel of output (4K, 2.0x:
+                                          66.8 vs 72.3 us; 1.5x: 80.7 vs 88.8), the fused launch below that, where a
+                                          frame is launch-bound (1080p output: 22.7 vs 28.2 us); packed-fp16 math always
+                                          runs as two dispatches; with intermediary == NULL it is the fused launch */
+  uint32_t flags;                      /* FSR1_FLAG_MATH_*, FSR1_FLAG_RCAS_DENOISE / _PASSTHROUGH_ALPHA, FSR1_FLAG_OUTPUT_* (of the pass that writes `out`) */
 } fsr1_params;
 
 /* in -> (intermediary) -> out.  `intermediary` may be NULL when use_rcas == 0 or fused == 1. */

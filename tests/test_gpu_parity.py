@@ -435,9 +435,10 @@ def test_exact_2x_fast_path_is_bit_identical(fsr, shape, fmt):
 
 
 def test_upscale_auto_pipeline(fsr, port):
-    """fsr1_params.fused = 2 picks the fused launch at 2x and the two dispatches at 1.5x; the image is the same either way
-    (fused == two-pass bit for bit), so only the choice itself needs checking: the intermediary is written iff two-pass ran."""
-    for (iw, ih, ow, oh), expect_two_pass in (((160, 90, 320, 180), False), ((160, 90, 240, 135), True)):
+    """fsr1_params.fused = 2 picks the fused launch where a frame is launch-bound (<= 3 Mpixel of output per launch) and the
+    two dispatches above (round-2 measurements, include/fsr1_hip.h); the image is the same either way (fused == two-pass
+    bit for bit), so only the choice itself needs checking: the intermediary is written iff two-pass ran."""
+    for (iw, ih, ow, oh), expect_two_pass in (((160, 90, 320, 180), False), ((160, 90, 240, 135), False), ((1280, 720, 2560, 1440), True)):
         src = dev(frames.synthetic_frame(iw, ih, k=2, dtype=np.float16))
         dst = torch.zeros(oh, ow, 4, dtype=torch.float16, device="cuda")
         filt = fsr.FSR_Filter()
