@@ -53,9 +53,14 @@ __device__ __forceinline__ void rcas_strip(const RcasArgs& a, int frame, int x0,
   // unconditionally (no exec-masked branch: the compiler then counts vmcnt exactly and keeps the prefetch depth)
   const int hcol = lane == 0 ? x0 - 1 : (lane == 63 ? x0 + kRcasWaveCols : col);
   const bool halo_ok = edge && (INTERIOR || (hcol >= 0 && hcol < W));
-  const char* const in_col = a.in.base + (long long)frame * a.in.frame_stride + (size_t)col * sizeof(texel_t);
-  const char* const in_hcol = a.in.base + (long long)frame * a.in.frame_stride + (size_t)hcol * sizeof(texel_t);
-  char* const out_col = a.out.base + (long long)frame * a.out.frame_stride + (size_t)col * sizeof(out_t);
+  // a row's address = wave-uniform 64-bit row base (scalar arithmetic) + a 32-bit lane offset: no 64-bit vector arithmetic
+  const char* const in_frame = a.in.base + (long long)frame * a.in.frame_stride;
+  char* const out_frame = a.out.base + (long long)frame * a.out.frame_stride;
+  const uint32_t off = (uint32_t)col * (uint32_t)sizeof(texel_t), hoff = (uint32_t)max(hcol, 0) * (uint32_t)sizeof(texel_t);
+  const uint32_t ooff = (uint32_t)col * (uint32_t)sizeof(out_t);
+  // keeps the zero-extension of a lane offset next to its use, where instruction selection can fold it into the
+  // `global_load / global_store v_off, s[base]` addressing form (hoisted out of the row loop it becomes a 64-bit add per access)
+  auto zext = [](uint32_t o) { asm("" : "+v"(o)); return (size_t)o; };
 
   const int rows = a.rows;
   auto row_y = [&](int k) { return UP ? y0 + rows - 1 - k : y0 + k; };  // k-th row of the walk, k = -1 .. rows
@@ -64,29 +69,29 @@ __device__ __forceinline__ void rcas_strip(const RcasArgs& a, int frame, int x0,
     if (!INTERIOR) r.halo = Pixel<FMT>::zero();
     if (INTERIOR) {
 #ifdef FSR1_RCAS_NT_LOAD  // tuning experiment
-      const pair_t pr = __builtin_nontemporal_load(reinterpret_cast<const pair_t*>(in_col + (long long)y * a.in.pitch));
+      const pair_t pr = __builtin_nontemporal_load(reinterpret_cast<const pair_t*>(in_frame + (long long)y * a.in.pitch + zext(off)));
 #else
-      const pair_t pr = *reinterpret_cast<const pair_t*>(in_col + (long long)y * a.in.pitch);
+      const pair_t pr = *reinterpret_cast<const pair_t*>(in_frame + (long long)y * a.in.pitch + zext(off));
 #endif
       __builtin_memcpy(&r.p0, &pr, sizeof(texel_t));
       __builtin_memcpy(&r.p1, reinterpret_cast<const char*>(&pr) + sizeof(texel_t), sizeof(texel_t));
 #ifdef FSR1_RCAS_NO_HALO  // timing experiment only (wrong at strip edges)
       r.halo = r.p0;
 #else
-      r.halo = *reinterpret_cast<const texel_t*>(in_hcol + (long long)y * a.in.pitch);
+      r.halo = *reinterpret_cast<const texel_t*>(in_frame + (long long)y * a.in.pitch + zext(hoff));
 #endif
     } else {
       r.p0 = Pixel<FMT>::zero();
       r.p1 = Pixel<FMT>::zero();
       if (y >= 0 && y < H) {  // wave-uniform
         if (ok1) {
-          const pair_t pr = *reinterpret_cast<const pair_t*>(in_col + (long long)y * a.in.pitch);
+          const pair_t pr = *reinterpret_cast<const pair_t*>(in_frame + (long long)y * a.in.pitch + zext(off));
           __builtin_memcpy(&r.p0, &pr, sizeof(texel_t));
           __builtin_memcpy(&r.p1, reinterpret_cast<const char*>(&pr) + sizeof(texel_t), sizeof(texel_t));
         } else if (ok0) {
-          r.p0 = *reinterpret_cast<const texel_t*>(in_col + (long long)y * a.in.pitch);
+          r.p0 = *reinterpret_cast<const texel_t*>(in_frame + (long long)y * a.in.pitch + zext(off));
         }
-        if (halo_ok) r.halo = *reinterpret_cast<const texel_t*>(in_hcol + (long long)y * a.in.pitch);
+        if (halo_ok) r.halo = *reinterpret_cast<const texel_t*>(in_frame + (long long)y * a.in.pitch + zext(hoff));
       }
     }
   };
@@ -95,11 +100,6 @@ __device__ __forceinline__ void rcas_strip(const RcasArgs& a, int frame, int x0,
     if constexpr (COLOR) c = color_prologue<EXACT>(a.color, c);
     return rgb_t{c.x, c.y, c.z};
   };
-  // Loop-carried fp32 values reach v_min/v_max through block boundaries, where the compiler no longer knows
-  // they are canonical and would spend a v_max_f32 x,x,x (4.3 cycles) on each; x+0.0 (2.4 cycles) tells it the
-  // same thing.  It turns -0 into +0, so the EXACT variant does not use it.
-  auto known = [](rgb_t v) { return EXACT ? v : rgb_t{v.r + 0.0f, v.g + 0.0f, v.b + 0.0f}; };
-
   // Ring of raw rows in registers: slot k holds row y0 + r with r % kRing == k; loads run kAhead = kRing - 1 rows
   // ahead of the arithmetic.  The row loop is unrolled by kRing, so every ring index is static, and rolled
   // beyond that so the body stays inside the instruction cache.
@@ -135,10 +135,8 @@ __device__ __forceinline__ void rcas_strip(const RcasArgs& a, int frame, int x0,
       (void)sharp;
 #else
       // b is the tap above, h the one below (ffx_fsr1.h:697-707): when walking up, `prev` is the row below
-      rgb_t o0 = UP ? rcas_pixel<EXACT>(next0, d0, known(cur0), known(cur1), known(prev0), sharp, flags)
-                    : rcas_pixel<EXACT>(known(prev0), d0, known(cur0), known(cur1), next0, sharp, flags);
-      rgb_t o1 = UP ? rcas_pixel<EXACT>(next1, known(cur0), known(cur1), f1, known(prev1), sharp, flags)
-                    : rcas_pixel<EXACT>(known(prev1), known(cur0), known(cur1), f1, next1, sharp, flags);
+      rgb_t o0 = UP ? rcas_pixel<EXACT>(next0, d0, cur0, cur1, prev0, sharp, flags) : rcas_pixel<EXACT>(prev0, d0, cur0, cur1, next0, sharp, flags);
+      rgb_t o1 = UP ? rcas_pixel<EXACT>(next1, cur0, cur1, f1, prev1, sharp, flags) : rcas_pixel<EXACT>(prev1, cur0, cur1, f1, next1, sharp, flags);
 #endif
       if (INTERIOR || y < H) {
         const bool alpha = (flags & FSR1_FLAG_RCAS_PASSTHROUGH_ALPHA) != 0;  // :700-705 / FSR_Pass.hlsl:94
@@ -148,7 +146,7 @@ __device__ __forceinline__ void rcas_strip(const RcasArgs& a, int frame, int x0,
         }
         const out_t t0 = Pixel<FOUT>::store(o0.r, o0.g, o0.b, alpha ? Pixel<FMT>::load(c.p0).w : 1.0f);
         const out_t t1 = Pixel<FOUT>::store(o1.r, o1.g, o1.b, alpha ? Pixel<FMT>::load(c.p1).w : 1.0f);
-        char* const dst = out_col + (long long)y * a.out.pitch;
+        char* const dst = out_frame + (long long)y * a.out.pitch + zext(ooff);
         if (ok1) {
           out_pair_t pr;
           __builtin_memcpy(&pr, &t0, sizeof(out_t));

@@ -16,21 +16,30 @@ __device__ __forceinline__ float dpp_f32(float keep, float v) {
   return as_f32((uint32_t)__builtin_amdgcn_update_dpp((int)as_u32(keep), (int)as_u32(v), CTRL, 0xf, 0xf, false));
 }
 
+// IEEE minNum / maxNum as single instructions on operands the compiler must not "canonicalise" first (see rcas_pixel)
+__device__ __forceinline__ float vmin3(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ float vmax3(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ float vmin2(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float vmax2(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+
 // One pixel of FsrRcasF from its 5 taps (b above, d left, e centre, f right, h below).
 template <bool EXACT>
 __device__ __forceinline__ rgb_t rcas_pixel(rgb_t b, rgb_t d, rgb_t e, rgb_t f, rgb_t h, float sharp, uint32_t flags) {  // flags: compile-time 0 in the plain variant
-  // :741-746 min and max of the ring, per channel
-  const float mn4R = fminf(min3f(b.r, d.r, f.r), h.r), mn4G = fminf(min3f(b.g, d.g, f.g), h.g), mn4B = fminf(min3f(b.b, d.b, f.b), h.b);
-  const float mx4R = fmaxf(max3f(b.r, d.r, f.r), h.r), mx4G = fmaxf(max3f(b.g, d.g, f.g), h.g), mx4B = fmaxf(max3f(b.b, d.b, f.b), h.b);
+  // :741-746 min and max of the ring, per channel.  v_min3 / v_max3 / v_min / v_max written out (vmin3 ... below): the taps
+  // reach this function from memory, from loop-carried registers and through DPP moves, where the compiler no longer
+  // knows they are canonical and would spend a `v_max_f32 x, x, x` on every one of them before fminf / fmaxf (18 extra
+  // instructions per two pixels in the streaming kernel).  The instructions themselves are IEEE minNum / maxNum.
+  const float mn4R = vmin2(vmin3(b.r, d.r, f.r), h.r), mn4G = vmin2(vmin3(b.g, d.g, f.g), h.g), mn4B = vmin2(vmin3(b.b, d.b, f.b), h.b);
+  const float mx4R = vmax2(vmax3(b.r, d.r, f.r), h.r), mx4G = vmax2(vmax3(b.g, d.g, f.g), h.g), mx4B = vmax2(vmax3(b.b, d.b, f.b), h.b);
   // :748-755 limiters; "these need to be high precision RCPs": IEEE division when EXACT, v_rcp_f32 (1 ulp) otherwise.
   // 4*x and 4*x-4 are exact scalings, so fusing the latter does not change it (barring overflow).
   auto rcp = [](float x) { return EXACT ? 1.0f / x : __builtin_amdgcn_rcpf(x); };
-  const float hitMinR = fminf(mn4R, e.r) * rcp(4.0f * mx4R);
-  const float hitMinG = fminf(mn4G, e.g) * rcp(4.0f * mx4G);
-  const float hitMinB = fminf(mn4B, e.b) * rcp(4.0f * mx4B);
-  const float hitMaxR = (1.0f - fmaxf(mx4R, e.r)) * rcp(fmaf(4.0f, mn4R, -4.0f));
-  const float hitMaxG = (1.0f - fmaxf(mx4G, e.g)) * rcp(fmaf(4.0f, mn4G, -4.0f));
-  const float hitMaxB = (1.0f - fmaxf(mx4B, e.b)) * rcp(fmaf(4.0f, mn4B, -4.0f));
+  const float hitMinR = vmin2(mn4R, e.r) * rcp(4.0f * mx4R);
+  const float hitMinG = vmin2(mn4G, e.g) * rcp(4.0f * mx4G);
+  const float hitMinB = vmin2(mn4B, e.b) * rcp(4.0f * mx4B);
+  const float hitMaxR = (1.0f - vmax2(mx4R, e.r)) * rcp(fmaf(4.0f, mn4R, -4.0f));
+  const float hitMaxG = (1.0f - vmax2(mx4G, e.g)) * rcp(fmaf(4.0f, mn4G, -4.0f));
+  const float hitMaxB = (1.0f - vmax2(mx4B, e.b)) * rcp(fmaf(4.0f, mn4B, -4.0f));
   // :756-759  max() must return the non-NaN operand (0*inf on black pixels): v_max_f32 does.
   const float lobeR = fmaxf(-hitMinR, hitMaxR), lobeG = fmaxf(-hitMinG, hitMaxG), lobeB = fmaxf(-hitMinB, hitMaxB);
   float lobe = fmaxf(-(0.25f - (1.0f / 16.0f)), fminf(max3f(lobeR, lobeG, lobeB), 0.0f)) * sharp;
