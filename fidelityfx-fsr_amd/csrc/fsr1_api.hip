@@ -7,6 +7,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <dlfcn.h>
 
 #include "fsr1_device.h"
 
@@ -41,6 +42,41 @@ __global__ void selftest_kernel(uint32_t* failures) {
   const bool both_nan = (fast != fast) && (ieee != ieee);
   if (fb != ib && !both_nan) atomicAdd(failures, 1u);
 }
+
+// Tracing: with FSR1_ROCTX=1 in the environment every dispatch is wrapped in a roctx range named
+// after the pass and its extents, so rocprofv3 --marker-trace / a timeline viewer shows the frame structure.  the roctx library
+// (librocprofiler-sdk-roctx / libroctx64) is resolved with dlopen on first use: the library has no link-time dependency on it and pays one branch when off.
+namespace {
+struct Roctx {
+  int (*push)(const char*) = nullptr;
+  int (*pop)() = nullptr;
+  Roctx() {
+    const char* e = getenv("FSR1_ROCTX");
+    if (!e || !*e || *e == '0') return;
+    void* h = nullptr;
+    for (const char* lib : {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so", "libroctx64.so.4"})
+      if ((h = dlopen(lib, RTLD_NOW | RTLD_GLOBAL))) break;
+    if (!h) return;
+    push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA"));
+    pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+    if (!push || !pop) push = nullptr, pop = nullptr;
+  }
+};
+struct Range {
+  bool on = false;
+  Range(const char* pass, const fsr1_image* in, const fsr1_image* out) {
+    static const Roctx r;
+    if (!r.push || !in || !out) return;
+    char name[96];
+    snprintf(name, sizeof name, "fsr1_%s %dx%d->%dx%d x%d", pass, in->width, in->height, out->width, out->height, out->frames);
+    r.push(name);
+    pop_ = r.pop;
+    on = true;
+  }
+  ~Range() { if (on) pop_(); }
+  int (*pop_)() = nullptr;
+};
+}  // namespace
 
 static thread_local char g_err[512] = "";
 
@@ -197,6 +233,7 @@ int fsr1_easu_dispatch(const fsr1_image* in, const fsr1_image* out, const uint32
 
 int fsr1_easu_dispatch_ex(const fsr1_image* in, const fsr1_image* out, const uint32_t con[16], uint32_t flags,
                           const fsr1_color_stages* stages, void* stream) {
+  const Range range("easu", in, out);
   EasuArgs a;
   int rc;
   if ((rc = check_flags(flags))) return rc;
@@ -258,6 +295,7 @@ int fsr1_rcas_dispatch(const fsr1_image* in, const fsr1_image* out, const uint32
 
 int fsr1_rcas_dispatch_ex(const fsr1_image* in, const fsr1_image* out, const uint32_t con[4], uint32_t flags,
                           const fsr1_color_stages* stages, void* stream) {
+  const Range range("rcas", in, out);
   RcasArgs a;
   int rc;
   if ((rc = check_flags(flags))) return rc;
@@ -298,6 +336,7 @@ int fsr1_easu_rcas_fused_dispatch(const fsr1_image* in, const fsr1_image* out, c
 int fsr1_easu_rcas_fused_dispatch_ex(const fsr1_image* in, const fsr1_image* out, const uint32_t easu_con[16],
                                      const uint32_t rcas_con[4], uint32_t flags, const fsr1_color_stages* stages,
                                      void* stream) {
+  const Range range("easu_rcas_fused", in, out);
   FusedArgs a;
   int rc;
   if ((rc = check_flags(flags))) return rc;
@@ -339,6 +378,7 @@ int fsr1_easu_rcas_fused_dispatch_ex(const fsr1_image* in, const fsr1_image* out
 // Stand-alone colour pass (ffx_fsr1.h:986-1199).
 int fsr1_color_dispatch(const fsr1_image* in, const fsr1_image* out, const fsr1_color_stages* stages, uint32_t flags,
                         void* stream) {
+  const Range range("color", in, out);
   ColorPassArgs a;
   int rc;
   if (flags & ~(uint32_t)(FSR1_FLAG_MATH_EXACT | FSR1_FLAG_MATH_PACKED_FP16))
@@ -376,6 +416,7 @@ int fsr1_upscale(const fsr1_image* in, const fsr1_image* intermediary, const fsr
 
 int fsr1_upscale_ex(const fsr1_image* in, const fsr1_image* intermediary, const fsr1_image* out, const fsr1_params* p,
                     const fsr1_color_stages* stages, void* stream) {
+  const Range range("upscale", in, out);
   if (!in || !out || !p) return fail(FSR1_ERR_INVALID_ARGUMENT, "upscale: null argument");
   if (!(p->render_width >= 1.0f) || !(p->render_height >= 1.0f) || p->render_width > (float)in->width || p->render_height > (float)in->height)
     return fail(FSR1_ERR_INVALID_ARGUMENT, "upscale: render size %gx%g must lie within the input image %dx%d", (double)p->render_width,

@@ -50,14 +50,24 @@ __global__ void __launch_bounds__(kThreads) rcas_h_kernel(const RcasArgs a) {
   const char* const in_frame = a.in.base + (long long)frame * a.in.frame_stride;
   char* const out_frame = a.out.base + (long long)frame * a.out.frame_stride;
 
-  // one row of this lane's pixel pair as structure-of-arrays, plus the apron texel broadcast to both halves
+  // a row's address = wave-uniform 64-bit row base + a 32-bit lane offset (see rcas_strip in fsr1_rcas_kernel.h)
+  const uint32_t off = (uint32_t)col * 8u, hoff = (uint32_t)max(hcol, 0) * 8u;
+  auto zext = [](uint32_t o) { asm("" : "+v"(o)); return (size_t)o; };
+  typedef TexelPair<FSR1_FORMAT_RGBA16F>::T pair_t;
+  // one row of this lane's pixel pair as structure-of-arrays, plus the apron texel broadcast to both halves; the pair is
+  // ONE 16-byte access (8-byte accesses run at 0.5-0.7 of the 16-byte rate on this chip)
   auto load = [&](int y, soa_t& own, soa_t& halo) {
     half4_t p0 = {0, 0, 0, 0}, p1 = {0, 0, 0, 0}, ph = {0, 0, 0, 0};
     if (y >= 0 && y < H) {  // wave-uniform
       const char* const row = in_frame + (long long)y * a.in.pitch;
-      if (ok0) p0 = *reinterpret_cast<const half4_t*>(row + (size_t)col * 8);
-      if (ok1) p1 = *reinterpret_cast<const half4_t*>(row + (size_t)(col + 1) * 8);
-      if (halo_ok) ph = *reinterpret_cast<const half4_t*>(row + (size_t)hcol * 8);
+      if (ok1) {
+        const pair_t pr = *reinterpret_cast<const pair_t*>(row + zext(off));
+        p0 = half4_t{pr[0], pr[1], pr[2], pr[3]};
+        p1 = half4_t{pr[4], pr[5], pr[6], pr[7]};
+      } else if (ok0) {
+        p0 = *reinterpret_cast<const half4_t*>(row + zext(off));
+      }
+      if (halo_ok) ph = *reinterpret_cast<const half4_t*>(row + zext(hoff));
     }
     own = soa_t{half2_t{p0.x, p1.x}, half2_t{p0.y, p1.y}, half2_t{p0.z, p1.z}, half2_t{p0.w, p1.w}};
     halo = soa_t{half2_t{ph.x, ph.x}, half2_t{ph.y, ph.y}, half2_t{ph.z, ph.z}, half2_t{ph.w, ph.w}};
@@ -95,11 +105,11 @@ __global__ void __launch_bounds__(kThreads) rcas_h_kernel(const RcasArgs a) {
     const half2_t pR = px.r, pG = px.g, pB = px.b;
     const half2_t pA = (flags & FSR1_FLAG_RCAS_PASSTHROUGH_ALPHA) ? e.a : one;       // :905-907 / FSR_Pass.hlsl:94
     if (y < H) {
-      char* const row = out_frame + (long long)y * a.out.pitch;
+      char* const row = out_frame + (long long)y * a.out.pitch + zext(off);
       // FsrRcasDepackHx2 :880-886
       const half4_t t0 = {pR.x, pG.x, pB.x, pA.x}, t1 = {pR.y, pG.y, pB.y, pA.y};
-      if (ok1) store_out<8>(row + (size_t)col * 8, TexelPair<FSR1_FORMAT_RGBA16F>::make(t0, t1), stream);
-      else if (ok0) store_out<8>(row + (size_t)col * 8, t0, stream);
+      if (ok1) store_out<8>(row, TexelPair<FSR1_FORMAT_RGBA16F>::make(t0, t1), stream);
+      else if (ok0) store_out<8>(row, t0, stream);
     }
     prev = e;
   }

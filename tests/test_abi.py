@@ -129,3 +129,15 @@ def test_upscale_parameter_validation(fsr):
     ok = P(16.0, 16.0, 1, 0.25, 0, 0, 1 << 8)        # NO_FAST_PATHS is a legal arithmetic-selection bit; no intermediary given
     assert lib.fsr1_upscale(ctypes.byref(a), None, ctypes.byref(b), ctypes.byref(ok), None) == -1
     assert b"intermediary" in lib.fsr1_last_error()
+
+
+@pytest.mark.gpu
+def test_roctx_ranges_can_be_switched_on():
+    """FSR1_ROCTX=1 wraps every dispatch in a roctx range (resolved with dlopen; SURVEY.md section 5 tracing): the smoke
+    upscale still matches the oracle with it on."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, FSR1_ROCTX="1")
+    out = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.smoke()"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "smoke ok" in out.stdout, out.stdout + out.stderr
