@@ -232,6 +232,19 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def close():
+        """Closing bracket of a timed region: synchronize, read this rank's clock, then barrier + synchronize.  The
+        region is bracketed by a barrier and a synchronize on both sides; the clock is read once this rank's K steps have
+        left the device and before the closing barrier's own latency (a few tens of microseconds of RCCL launch, which
+        at the driver's K = 20 would be several percent of the region) — the MAX over ranks, taken by reduce_counters,
+        is then the time at which the slowest rank finished its K steps."""
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+        return t
+
     # Device clock ramp (not part of W): an idle MI355X sits at ~100 MHz and needs a few milliseconds of load
     # to reach its working clocks; EASU then runs AT the 1400 W package power cap (sclk ~2.1 of 2.4 GHz), so the
     # steady state is what a frame stream sees.  ~0.2 s of the same steps, untimed.
@@ -257,14 +270,12 @@ def main():
         t0 = time.perf_counter()
         for _ in range(args.steps // args.graph):
             g.replay()
-        fence()
-        seconds = time.perf_counter() - t0
+        seconds = close() - t0
     else:
         t0 = time.perf_counter()
         for i in range(args.steps):
             step(args.warmup + i)
-        fence()
-        seconds = time.perf_counter() - t0
+        seconds = close() - t0
 
     total = reduce_counters(frames * args.steps, frames * args.steps * out_w * out_h, seconds, device)
     value = total["pixels"] / total["seconds"] / 1e6
@@ -282,8 +293,7 @@ def main():
         t0 = time.perf_counter()
         for i in range(args.steps):
             fused_step(i)
-        fence()
-        tf = reduce_counters(frames * args.steps, frames * args.steps * out_w * out_h, time.perf_counter() - t0, device)
+        tf = reduce_counters(frames * args.steps, frames * args.steps * out_w * out_h, close() - t0, device)
         also = {"fused": {"value": round(tf["pixels"] / tf["seconds"] / 1e6, 1), "unit": "Mpix/s",
                           "ms_per_step": round(tf["seconds"] * 1e3 / args.steps, 5),
                           "note": "EASU->RCAS in one launch, output bit-identical to the two dispatches (BASELINE configs[3])"}}
@@ -300,8 +310,7 @@ def main():
             t0 = time.perf_counter()
             for i in range(args.steps):
                 h_step(i)
-            fence()
-            th = reduce_counters(frames * args.steps, frames * args.steps * out_w * out_h, time.perf_counter() - t0, device)
+            th = reduce_counters(frames * args.steps, frames * args.steps * out_w * out_h, close() - t0, device)
             also["packed_fp16_two_pass"] = {"value": round(th["pixels"] / th["seconds"] / 1e6, 1), "unit": "Mpix/s",
                                             "ms_per_step": round(th["seconds"] * 1e3 / args.steps, 5),
                                             "note": "FsrEasuH + FsrRcasH (parity class H: bit-exact vs the reference's packed-fp16 path; "
