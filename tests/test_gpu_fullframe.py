@@ -221,3 +221,24 @@ def test_batch_1440p_to_4k_x8_all_frames(fsr, checker):
 def test_batch_4k_to_8k_x16_all_frames(fsr, checker):
     """BASELINE configs[4]'s per-GPU shard: 16 frames of 3840x2160 -> 7680x4320 in one launch, every frame checked whole."""
     _batch(fsr, checker, "4k_to_8k", 16, ("two-pass", "fused"))
+
+
+def test_dynamic_resolution_whole_frame(fsr, checker):
+    """FsrEasuConOffset (ffx_fsr1.h:205-225): a 1600x900 viewport at offset (160, 90) inside a 1920x1080 resource,
+    upscaled to 3840x2160 — taps near the viewport's border read real texels of the resource, not clamped ones, and the
+    clamp happens at the RESOURCE edge (ffx_fsr1.h:161-166).  Whole frame, EXACT = 0 differing values, default <= 1 ULP."""
+    rw, rh, vw, vh, offx, offy, ow, oh = 1920, 1080, 1600, 900, 160.0, 90.0, 3840, 2160
+    img = frames.synthetic_frame(rw, rh, k=5, dtype=np.float16)
+    con = checker.FsrEasuConOffset(vw, vh, rw, rh, ow, oh, offx, offy)
+    assert np.array_equal(con, fsr.FsrEasuConOffset(vw, vh, rw, rh, ow, oh, offx, offy))
+    want = checker.easu_f(img.astype(np.float32), ow, oh, con)
+    src = dev(img)
+    out = torch.zeros(oh, ow, 4, dtype=torch.float16, device="cuda")
+    fsr.easu(src, out, con=con, flags=fsr.FLAG_MATH_EXACT)
+    assert_exact16(host(out), want, "dynamic resolution EXACT")
+    out.zero_()
+    fsr.easu(src, out, con=con)
+    assert_f_class(host(out), want, "dynamic resolution F")
+    out.zero_()
+    fsr.easu(src, out, con=con, flags=fsr.FLAG_MATH_PACKED_FP16)
+    assert_exact16(host(out), checker.easu_h(img.astype(np.float32), ow, oh, con), "dynamic resolution H")

@@ -49,3 +49,21 @@ def test_counter_reduction_gloo_world2(tmp_path):
                          cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert out.stdout.count("ok") == 2
+
+
+@pytest.mark.gpu
+def test_bench_two_gpus_over_rccl():
+    """bench.py --gpus 2 launched the way the driver launches it (one process per GPU, RCCL): skipped on a single-GPU box."""
+    import json
+    import subprocess
+    import sys
+    torch = pytest.importorskip("torch")
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two visible GPUs")
+    from conftest import ROOT
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29517",
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "50", "--warmup", "10", "--no-cpu-baseline", "--workload", "540p_to_1080p"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["value"] > 0
