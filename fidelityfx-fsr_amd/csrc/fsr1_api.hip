@@ -18,6 +18,8 @@ hipError_t rcas_launch(const RcasArgs& a, int fmt, bool exact, hipStream_t strea
 void rcas_geometry(int width, int height, int frames, int* tiles_x, int* tiles_y, int* rows);
 hipError_t fused_launch(const FusedArgs& a, int fmt, bool exact, hipStream_t stream);
 size_t fused_lds_bytes(int fmt, int fp_w, int fp_h);
+hipError_t fused_h_launch(const FusedArgs& a, hipStream_t stream);
+size_t fused_h_lds_bytes(int fp_w, int fp_h);
 hipError_t easu_h_launch(const EasuArgs& a, bool s2, hipStream_t stream);
 hipError_t easu_color_launch(const EasuArgs& a, int fin, int fout, bool exact, hipStream_t stream);
 hipError_t rcas_color_launch(const RcasArgs& a, int fin, int fout, bool exact, hipStream_t stream);
@@ -348,7 +350,9 @@ int fsr1_easu_rcas_fused_dispatch_ex(const fsr1_image* in, const fsr1_image* out
     return fail(FSR1_ERR_UNSUPPORTED, "fused: unsupported input/output format pair %d -> %d", in->format, out->format);
   if (in->frames != out->frames) return fail(FSR1_ERR_INVALID_ARGUMENT, "fused: frame counts differ (%d vs %d)", in->frames, out->frames);
   if (overlaps(in, a.in, out, a.out)) return fail(FSR1_ERR_INVALID_ARGUMENT, "fused: input and output overlap");
-  if (flags & FSR1_FLAG_MATH_PACKED_FP16) return fail(FSR1_ERR_UNSUPPORTED, "fused: packed-fp16 math is not available in the fused kernel");
+  const bool packed = (flags & FSR1_FLAG_MATH_PACKED_FP16) != 0;
+  if (packed && (in->format != FSR1_FORMAT_RGBA16F || a.color.stages))
+    return fail(FSR1_ERR_UNSUPPORTED, "fused: packed-fp16 math needs RGBA16F images and runs without colour stages");
   memcpy(a.easu_con, easu_con, sizeof a.easu_con);
   memcpy(a.rcas_con, rcas_con, sizeof a.rcas_con);
   float sx, sy, bx, by;
@@ -359,7 +363,7 @@ int fsr1_easu_rcas_fused_dispatch_ex(const fsr1_image* in, const fsr1_image* out
   a.fp_w = footprint_extent(out->width, kTileW, 1, sx, bx);
   a.fp_h = footprint_extent(out->height, kFusedTileH, 1, sy, by);
   if (a.fp_w < 0 || a.fp_h < 0) return fail(FSR1_ERR_INVALID_ARGUMENT, "fused: scale constants con0.xy = (%g, %g) are not usable", sx, sy);
-  if (fused_lds_bytes(in->format, a.fp_w, a.fp_h) > 160 * 1024)
+  if ((packed ? fused_h_lds_bytes(a.fp_w, a.fp_h) : fused_lds_bytes(in->format, a.fp_w, a.fp_h)) > 160 * 1024)
     return fail(FSR1_ERR_UNSUPPORTED, "fused: input/output ratio (%g, %g) needs more LDS than a CU has", sx, sy);
   if ((long long)(a.fp_h + 1) * a.in.pitch >= (1ll << 31))
     return fail(FSR1_ERR_UNSUPPORTED, "fused: input row pitch %lld too large for a %d-row footprint", a.in.pitch, a.fp_h);
@@ -369,8 +373,9 @@ int fsr1_easu_rcas_fused_dispatch_ex(const fsr1_image* in, const fsr1_image* out
   if ((rc = check_grid("fused", a.tiles_x, a.tiles_y, a.frames))) return rc;
   a.flags = resolve_output_policy(flags, true);
   const bool exact = (flags & FSR1_FLAG_MATH_EXACT) != 0;
-  hipError_t e = a.color.stages ? fused_color_launch(a, in->format, out->format, exact, static_cast<hipStream_t>(stream))
-                                : fused_launch(a, in->format, exact, static_cast<hipStream_t>(stream));
+  hipError_t e = packed ? fused_h_launch(a, static_cast<hipStream_t>(stream))
+                 : a.color.stages ? fused_color_launch(a, in->format, out->format, exact, static_cast<hipStream_t>(stream))
+                                  : fused_launch(a, in->format, exact, static_cast<hipStream_t>(stream));
   if (e != hipSuccess) return hip_fail(e, "fused launch");
   return FSR1_OK;
 }
@@ -441,10 +446,6 @@ int fsr1_upscale_ex(const fsr1_image* in, const fsr1_image* intermediary, const 
   if (p->fused == 2) {  // auto, on round-2 measurements: the fused launch pays off only where a frame is launch-bound
     const long long out_pixels = (long long)out->width * (long long)out->height * (long long)out->frames;
     fused = !intermediary || out_pixels <= 3000000ll;
-    if (math & FSR1_FLAG_MATH_PACKED_FP16) {  // FsrEasuH / FsrRcasH exist as two dispatches only
-      if (!intermediary) return fail(FSR1_ERR_INVALID_ARGUMENT, "upscale: packed-fp16 math runs as two dispatches and needs an intermediary image");
-      fused = false;
-    }
   } else if (p->fused != 0 && p->fused != 1) {
     return fail(FSR1_ERR_INVALID_ARGUMENT, "upscale: params.fused must be 0, 1 or 2 (auto)");
   }

@@ -138,6 +138,108 @@ __device__ __forceinline__ rgbh_t easu_filter_h(const Ana& ana, const PairFn& pa
   return rgbh_t{hmin1(bothR.y, hmax1(-bothR.x, aR * rW)), hmin1(bothG.y, hmax1(-bothG.x, aG * rW)), hmin1(bothB.y, hmax1(-bothB.x, aB * rW))};
 }
 
+// ---- the LDS-staged form of FsrEasuH (what the library's H kernels run) ----
+// LDS per footprint texel (48 bytes):
+//   tex1  half4  R G B luma of the texel                                   (phase 1; luma = B*0.5 + (R*0.5 + G), :535-538)
+//   texP  4 x half2  (R,G,B,luma) paired with the texel to the right       -> one ds_read_b128 per two-tap FsrEasuTapH call
+//   ana1  half4  dirX dirY lenX lenY of FsrEasuSetH for the '+' around the texel (:476-503: they do not depend on the
+//                output pixel, only their bilinear weights do), each a single binary16 operation sequence in the
+//                reference's order, so the per-pixel accumulation that follows sees bit-identical operands
+//   both  3 x half2  (max of -x, max of x) over the 2x2 block at the texel, per channel (:575-577)
+struct EasuHLds {
+  half4_t* tex1;
+  uint4* texP;
+  half4_t* ana1;
+  uint4* both;
+};
+
+// Phases 1 and 2 of the H kernel for the footprint [fx0, fx0+fw) x [fy0, fy0+fh).  FW, FH: compile-time extent (exact 2x).
+// THREADS: threads of the workgroup, all of which must make the call (it contains two barriers).
+template <int FW, int FH, int THREADS = 256>
+__device__ __forceinline__ void easu_h_stage(const EasuHLds& l, const ImageView& in, const char* in_frame, int fx0, int fy0, int fw_rt, int fh_rt, int tid) {
+  const int fw = FW ? FW : fw_rt, fh = FH ? FH : fh_rt;
+  const int n = fw * fh - 1;  // the bottom-right corner texel is touched by no 12-tap window (no (2, 2) tap)
+  const float inv_fw = 1.0f / (float)fw;
+  auto row_of = [&](int i) { return FW ? i / FW : (int)(((float)i + 0.5f) * inv_fw); };
+  {  // ---- phase 1: HBM -> LDS (clamp-to-edge applied), luma once per input texel; row base + 32-bit lane offsets ----
+    const int gy0 = min(max(fy0, 0), in.height - 1);
+    const char* const base = in_frame + (long long)gy0 * in.pitch;
+    const uint32_t pitch = (uint32_t)in.pitch;
+    const half_t hlf = (half_t)0.5f;
+    auto stage = [&](int i, uint32_t off) {
+      const half4_t c = *reinterpret_cast<const half4_t*>(base + (size_t)off);
+      l.tex1[i] = half4_t{c.x, c.y, c.z, (half_t)(c.z * hlf + (c.x * hlf + c.y))};  // :535-538
+    };
+    if (fx0 >= 0 && fy0 >= 0 && fx0 + fw <= in.width && fy0 + fh <= in.height) {  // wave-uniform: nothing to clamp
+      const uint32_t x_off = (uint32_t)fx0 * 8u;
+      for (int i = tid; i < n; i += THREADS) {
+        const int ly = row_of(i);
+        stage(i, (uint32_t)ly * pitch + (uint32_t)(i - ly * fw) * 8u + x_off);
+      }
+    } else {
+      for (int i = tid; i < n; i += THREADS) {
+        const int ly = row_of(i);
+        const int gy = min(max(fy0 + ly, 0), in.height - 1);
+        const int gx = min(max(fx0 + (i - ly * fw), 0), in.width - 1);
+        stage(i, (uint32_t)(gy - gy0) * pitch + (uint32_t)gx * 8u);
+      }
+    }
+  }
+  __syncthreads();
+  // ---- phase 2a: (texel, right neighbour) pairs — read as the left element by taps in columns 0 .. fw-2 of every row
+  //      (an entry in the last column pairs with the next row's first texel and is never read) ----
+  for (int i = tid; i < n - 1; i += THREADS) {
+    const half4_t tc = l.tex1[i], tr = l.tex1[i + 1];
+    l.texP[i] = uint4{as_u(h2(tc.x, tr.x)), as_u(h2(tc.y, tr.y)), as_u(h2(tc.z, tr.z)), as_u(h2(tc.w, tr.w))};
+  }
+  // ---- phase 2b: per-texel terms of the texels read as f / g / j / k of some pixel: columns 1..fw-2, rows 1..fh-2
+  //      (every neighbour of those lies inside the footprint, so nothing is clamped) ----
+  const int iw = fw - 2, m = iw * (fh - 2);
+  const float inv_iw = 1.0f / (float)iw;
+  for (int j = tid; j < m; j += THREADS) {
+    const int y = FW ? j / (FW - 2) : (int)(((float)j + 0.5f) * inv_iw);
+    const int i = (y + 1) * fw + (j - y * iw) + 1;
+    const half4_t tc = l.tex1[i], tr = l.tex1[i + 1], td = l.tex1[i + fw];
+    l.ana1[i] = easu_analysis_h(l.tex1[i - fw].w, l.tex1[i - 1].w, tc.w, tr.w, td.w);  // FsrEasuSetH :486-502, one AH2 lane
+    if (i + fw + 1 < n) {  // the 2x2 block at the last interior texel would reach the unstaged corner; no pixel has that texel as 'f'
+      const half4_t tdr = l.tex1[i + fw + 1];
+      // :575-577 min and max of the 2x2 block f g / j k through max() of (-x, x) pairs
+      const half2_t bR = easu_both_h(tc.x, tr.x, td.x, tdr.x), bG = easu_both_h(tc.y, tr.y, td.y, tdr.y), bB = easu_both_h(tc.z, tr.z, td.z, tdr.z);
+      l.both[i] = uint4{as_u(bR), as_u(bG), as_u(bB), 0u};
+    }
+  }
+  __syncthreads();
+}
+
+// FsrEasuH for the pixel whose 'f' texel sits at footprint index f, sub-texel position ppp (= AH2(pp), :516).
+__device__ __forceinline__ half4_t easu_h_pixel(const EasuHLds& l, int f, int fw, half2_t ppp, bool hdr) {
+  // texP[t] holds (t, t+1), so the reference's pairs bc / ij / kl come as stored and fe / hg / on are the swapped
+  // (e,f) / (g,h) / (n,o)
+  const uint4 bo = l.both[f];
+  const rgbh_t px = easu_filter_h(
+      [&](int k) { return l.ana1[f + (k >> 1) * fw + (k & 1)]; },
+      [&](int i) {
+        const int at[6] = {f - fw, f + fw - 1, f - 1, f + fw + 1, f + 1, f + 2 * fw};
+        const uint4 t = l.texP[at[i]];
+        const bool sw = i == 2 || i == 4 || i == 5;
+        return sw ? EasuHPair{swap2(as_h2(t.x)), swap2(as_h2(t.y)), swap2(as_h2(t.z))} : EasuHPair{as_h2(t.x), as_h2(t.y), as_h2(t.z)};
+      },
+      [&](int c) { return as_h2(c == 0 ? bo.x : (c == 1 ? bo.y : bo.z)); }, ppp);
+  half_t pr = px.r, pg = px.g, pb = px.b;
+  if (hdr) { pr = pr * pr; pg = pg * pg; pb = pb * pb; }  // FSR_Pass.hlsl:78-79
+  return half4_t{pr, pg, pb, (half_t)1.0f};              // alpha = 1, FSR_Pass.hlsl:80
+}
+
+constexpr int kEasuHLdsPerTexel = 48;
+__device__ __forceinline__ EasuHLds easu_h_lds_carve(char* smem, int capacity_texels) {
+  EasuHLds l;
+  l.texP = reinterpret_cast<uint4*>(smem);
+  l.both = reinterpret_cast<uint4*>(smem + (size_t)capacity_texels * 16);
+  l.tex1 = reinterpret_cast<half4_t*>(smem + (size_t)capacity_texels * 32);
+  l.ana1 = reinterpret_cast<half4_t*>(smem + (size_t)capacity_texels * 40);
+  return l;
+}
+
 // ---- RCAS, two pixels per call in the two halves of every operand (FsrRcasHx2's arithmetic, :913-984) ----
 struct soa_t { half2_t r, g, b, a; };  // two pixels: .x = left (even column), .y = right
 

@@ -212,8 +212,9 @@ typedef struct fsr1_params {
                                           2: whichever is faster on MI355X, decided on round-2 measurements: the two
                                           dispatches whenever the launch has more than 3 Mpixel of output (4K, 2.0x:
                                           66.8 vs 72.3 us; 1.5x: 80.7 vs 88.8), the fused launch below that, where a
-                                          frame is launch-bound (1080p output: 22.7 vs 28.2 us); packed-fp16 math always
-                                          runs as two dispatches; with intermediary == NULL it is the fused launch */
+                                          frame is launch-bound (1080p output: 22.7 vs 28.2 us), for every arithmetic
+                                          (FSR1_FLAG_MATH_PACKED_FP16 has a fused launch too); with intermediary == NULL it
+                                          is the fused launch */
   uint32_t flags;                      /* FSR1_FLAG_MATH_*, FSR1_FLAG_RCAS_DENOISE / _PASSTHROUGH_ALPHA, FSR1_FLAG_OUTPUT_* (of the pass that writes `out`) */
 } fsr1_params;
 

@@ -296,8 +296,8 @@ int main(int argc, char** argv) {
   const int visible = fsr1_device_count();
   if (visible < 0) { fprintf(stderr, "cannot enumerate GPUs: %s\n", fsr1_last_error()); return 1; }
   if (visible < o.gpus) { fprintf(stderr, "need %d GPUs, %d visible\n", o.gpus, visible); return 1; }
-  if ((o.math & FSR1_FLAG_MATH_PACKED_FP16) && (o.pipeline == 1 || o.stages)) {
-    fprintf(stderr, "--math h (FsrEasuH / FsrRcasH) runs as two dispatches without colour stages\n");
+  if ((o.math & FSR1_FLAG_MATH_PACKED_FP16) && o.stages) {
+    fprintf(stderr, "--math h (FsrEasuH / FsrRcasH) runs without colour stages\n");
     return 2;
   }
 

@@ -154,6 +154,9 @@ def test_whole_frame_packed_fp16(fsr, checker, name):
     got_mid = host(mid)
     assert_exact16(got_mid, checker.easu_h(img.astype(np.float32), ow, oh, con), name + " easu H")
     assert_exact16(host(out), checker.rcas_h(got_mid.astype(np.float32), rc), name + " rcas H")
+    fus = torch.zeros_like(mid)
+    fsr.easu_rcas_fused(src, fus, easu_con=con, rcas_con=rc, flags=fsr.FLAG_MATH_PACKED_FP16)
+    assert torch.equal(out.view(torch.int16), fus.view(torch.int16)), name + ": fused H launch differs from the two H dispatches"
 
 
 @pytest.mark.parametrize("name", ["1080p_to_4k", "1440p_to_4k"])

@@ -178,18 +178,56 @@ def test_easu_h_exact_2x_variant_is_bit_identical(fsr, port, shape):
 
 def test_upscale_auto_with_packed_fp16(fsr, port):
     """FSR_Filter.OnCreate(slowFallback=False, fused="auto") — the reference's default permutation with the pipeline left
-    to the library — at exactly 2x: the packed-fp16 entry points exist as two dispatches only, so `auto` must take them
-    (round 1 routed this to the fused launch, which rejects packed-fp16)."""
-    iw, ih, ow, oh = 160, 90, 320, 180
-    img = frames.synthetic_frame(iw, ih, k=6, dtype=np.float16)
-    src = dev(img)
-    dst = torch.zeros(oh, ow, 4, dtype=torch.float16, device="cuda")
-    filt = fsr.FSR_Filter()
-    filt.OnCreate(slowFallback=False, fused="auto")
-    filt.OnCreateWindowSizeDependentResources(src, dst, ow, oh)
-    filt.Upscale(ow, oh, fsr.State(iw, ih, bUseRcas=True, rcasAttenuation=0.25))
-    con = port.FsrEasuCon(iw, ih, iw, ih, ow, oh)
-    mid = host(filt.m_intermediary).reshape(oh, ow, 4)
-    assert_bits16(mid, port.easu_h(img.astype(np.float32), ow, oh, con), "auto + packed fp16: easu")
-    assert_bits16(host(dst), port.rcas_h(mid.astype(np.float32), port.FsrRcasCon(0.25)), "auto + packed fp16: rcas")
-    filt.OnDestroy()
+    to the library (round 1 failed here: auto picked a fused launch that did not exist for packed-fp16).  A small frame takes
+    the fused H launch, a frame above 3 Mpixel the two H dispatches; either way the image is FsrRcasH(FsrEasuH(input))."""
+    for (iw, ih, ow, oh), expect_two_pass in (((160, 90, 320, 180), False), ((1280, 720, 2560, 1440), True)):
+        img = frames.synthetic_frame(iw, ih, k=6, dtype=np.float16)
+        src = dev(img)
+        dst = torch.zeros(oh, ow, 4, dtype=torch.float16, device="cuda")
+        filt = fsr.FSR_Filter()
+        filt.OnCreate(slowFallback=False, fused="auto")
+        filt.OnCreateWindowSizeDependentResources(src, dst, ow, oh)
+        filt.m_intermediary.fill_(-1.0)
+        filt.Upscale(ow, oh, fsr.State(iw, ih, bUseRcas=True, rcasAttenuation=0.25))
+        assert bool((host(filt.m_intermediary) != -1.0).any()) == expect_two_pass
+        con = port.FsrEasuCon(iw, ih, iw, ih, ow, oh)
+        mid = port.easu_h(img.astype(np.float32), ow, oh, con)
+        assert_bits16(host(dst), port.rcas_h(mid, port.FsrRcasCon(0.25)), "auto + packed fp16 %dx%d" % (ow, oh))
+        filt.OnDestroy()
+
+
+@pytest.mark.parametrize("shape", [(160, 90, 320, 180), (97, 61, 131, 83), (1, 1, 2, 2), (33, 9, 66, 18), (200, 120, 300, 180), (64, 40, 256, 160)],
+                         ids=lambda s: "%dx%d_to_%dx%d" % s)
+def test_fused_h_equals_two_pass_h(fsr, shape):
+    """The single-launch H pipeline (FsrEasuH -> LDS -> FsrRcasH) stores the very image of the two H dispatches, for every
+    RCAS option, incl. ragged tiles, the 1x1 input and ratios other than 2x."""
+    iw, ih, ow, oh = shape
+    src = dev(frames.synthetic_frame(iw, ih, k=4, dtype=np.float16))
+    h = fsr.FLAG_MATH_PACKED_FP16
+    for opts in (0, fsr.FLAG_RCAS_DENOISE, fsr.FLAG_RCAS_PASSTHROUGH_ALPHA, fsr.FLAG_HDR_SQUARE, fsr.FLAG_RCAS_DENOISE | fsr.FLAG_HDR_SQUARE):
+        mid = torch.zeros(oh, ow, 4, dtype=torch.float16, device="cuda")
+        two = torch.zeros_like(mid)
+        one = torch.zeros_like(mid)
+        fsr.easu(src, mid, flags=h)
+        fsr.rcas(mid, two, sharpness=0.5, flags=h | opts)
+        fsr.easu_rcas_fused(src, one, sharpness=0.5, flags=h | opts)
+        assert torch.equal(one.view(torch.int16), two.view(torch.int16)), "fused H differs from two-pass H (opts %d)" % opts
+
+
+def test_fused_h_batch_with_pitches(fsr):
+    n, iw, ih, ow, oh = 3, 70, 37, 140, 74
+    big_in = torch.zeros(n, ih + 2, iw + 3, 4, dtype=torch.float16, device="cuda")
+    src = big_in[:, :ih, :iw]
+    for f in range(n):
+        src[f].copy_(dev(frames.synthetic_frame(iw, ih, k=20 + f, dtype=np.float16)))
+    h = fsr.FLAG_MATH_PACKED_FP16
+    mid = torch.zeros(n, oh, ow, 4, dtype=torch.float16, device="cuda")
+    two = torch.zeros_like(mid)
+    big_out = torch.full((n, oh + 1, ow + 5, 4), -3.0, dtype=torch.float16, device="cuda")
+    one = big_out[:, :oh, :ow]
+    fsr.easu(src, mid, flags=h)
+    fsr.rcas(mid, two, flags=h)
+    fsr.easu_rcas_fused(src, one, flags=h)
+    torch.cuda.synchronize()
+    assert torch.equal(one, two)
+    assert float((big_out[:, oh:] != -3.0).sum()) == 0 and float((big_out[:, :, ow:] != -3.0).sum()) == 0  # padding untouched

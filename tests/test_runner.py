@@ -54,7 +54,10 @@ def test_runner_packed_fp16_and_ring(runner):
     assert out.returncode == 0, out.stdout + out.stderr
     d = json.loads(out.stdout.strip().splitlines()[-1])
     assert d["math"] == "h" and d["ring"] == 3 and d["frames"] == 24 and d["value"] > 500.0
-    bad = subprocess.run([runner, "--math", "h", "--pipeline", "fused"], capture_output=True, text=True, timeout=60)
+    fused = subprocess.run([runner, "--gpus", "1", "--frames", "1", "--in", "320x180", "--out", "640x360", "--steps", "5", "--warmup", "1",
+                            "--math", "h", "--pipeline", "fused"], capture_output=True, text=True, timeout=300)
+    assert fused.returncode == 0, fused.stdout + fused.stderr
+    bad = subprocess.run([runner, "--math", "h", "--stages", "2"], capture_output=True, text=True, timeout=60)
     assert bad.returncode == 2
 
 
