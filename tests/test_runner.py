@@ -29,7 +29,7 @@ def test_runner_builds_and_parses_arguments(runner):
 @pytest.mark.parametrize("pipeline", ["two-pass", "fused", "easu", "auto"])
 def test_runner_on_gpu(runner, pipeline):
     out = subprocess.run([runner, "--gpus", "1", "--frames", "3", "--in", "640x360", "--out", "1280x720", "--steps", "20",
-                          "--warmup", "3", "--pipeline", pipeline], capture_output=True, text=True, timeout=300)
+                          "--warmup", "3", "--pipeline", pipeline], capture_output=True, text=True, timeout=1200)
     assert out.returncode == 0, out.stdout + out.stderr
     d = json.loads(out.stdout.strip().splitlines()[-1])
     assert d["n_gpus"] == 1 and d["frames"] == 60 and d["pipeline"] == pipeline
@@ -40,7 +40,7 @@ def test_runner_on_gpu(runner, pipeline):
 def test_runner_with_colour_stages(runner):
     """--stages: SRTM prologue + film grain + SRTM inverse fused into the single-launch pipeline, from the C host."""
     out = subprocess.run([runner, "--gpus", "1", "--frames", "2", "--in", "640x360", "--out", "1280x720", "--steps", "10",
-                          "--warmup", "2", "--pipeline", "fused", "--stages", "7", "--grain", "0.3"], capture_output=True, text=True, timeout=300)
+                          "--warmup", "2", "--pipeline", "fused", "--stages", "7", "--grain", "0.3"], capture_output=True, text=True, timeout=1200)
     assert out.returncode == 0, out.stdout + out.stderr
     d = json.loads(out.stdout.strip().splitlines()[-1])
     assert d["color_stages"] == 7 and d["frames"] == 20 and d["value"] > 1000.0
@@ -50,12 +50,12 @@ def test_runner_with_colour_stages(runner):
 def test_runner_packed_fp16_and_ring(runner):
     """--math h drives FsrEasuH / FsrRcasH from the C host; --ring rotates the steps over several frame sets."""
     out = subprocess.run([runner, "--gpus", "1", "--frames", "2", "--in", "640x360", "--out", "1280x720", "--steps", "12",
-                          "--warmup", "2", "--math", "h", "--ring", "3"], capture_output=True, text=True, timeout=300)
+                          "--warmup", "2", "--math", "h", "--ring", "3"], capture_output=True, text=True, timeout=1200)
     assert out.returncode == 0, out.stdout + out.stderr
     d = json.loads(out.stdout.strip().splitlines()[-1])
     assert d["math"] == "h" and d["ring"] == 3 and d["frames"] == 24 and d["value"] > 500.0
     fused = subprocess.run([runner, "--gpus", "1", "--frames", "1", "--in", "320x180", "--out", "640x360", "--steps", "5", "--warmup", "1",
-                            "--math", "h", "--pipeline", "fused"], capture_output=True, text=True, timeout=300)
+                            "--math", "h", "--pipeline", "fused"], capture_output=True, text=True, timeout=1200)
     assert fused.returncode == 0, fused.stdout + fused.stderr
     bad = subprocess.run([runner, "--math", "h", "--stages", "2"], capture_output=True, text=True, timeout=60)
     assert bad.returncode == 2
@@ -69,7 +69,7 @@ def test_runner_two_gpus_over_rccl(runner, fsr):
     if fsr.load().fsr1_device_count() < 2:
         pytest.skip("needs two visible GPUs")
     out = subprocess.run([runner, "--gpus", "2", "--frames", "5", "--in", "960x540", "--out", "1920x1080", "--steps", "20",
-                          "--warmup", "3"], capture_output=True, text=True, timeout=300)
+                          "--warmup", "3"], capture_output=True, text=True, timeout=1200)
     assert out.returncode == 0, out.stdout + out.stderr
     d = json.loads(out.stdout.strip().splitlines()[-1])
     assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["frames"] == 100 and len(d["per_gpu_ms"]) == 2
