@@ -66,7 +66,7 @@ def child(args):
 
         n = max(10, int(args.launches / max(1, frames)))
         row = {"lib": os.path.basename(os.environ.get("FSR1_HIP_LIB", "default")), "workload": wl, "math": args.math}
-        for name, fn in (("easu", easu), ("rcas", rcas), ("pair", pair)) + ((("fused", fused),) if args.math != "h" else ()):
+        for name, fn in (("easu", easu), ("rcas", rcas), ("pair", pair), ("fused", fused)):
             if name in args.kernels.split(","):
                 row[name + "_us"] = round(ms(fn, n) * 1e3, 2)
         print(json.dumps(row), flush=True)
