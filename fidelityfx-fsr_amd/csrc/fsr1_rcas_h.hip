@@ -6,7 +6,7 @@
 // arithmetic), one native binary16 operation per reference operation, contraction off — bit-identical
 // to the reference's FsrRcasH evaluated on the CPU with round-to-nearest-even after every operation.
 //
-// Streaming structure of the fp32 kernel (fsr1_rcas.hip): no LDS, a wave owns a 128-column x 24-row strip,
+// Streaming structure of the fp32 kernel (fsr1_rcas.hip): no LDS, a wave owns a 128-column x 8-row strip,
 // rows flow through registers (b = previous row, h = next row), the horizontal neighbours of a lane's
 // pixel pair are its own other pixel and the adjacent lane's facing pixel (DPP wave shift); lanes 0 / 63
 // also load the strip's apron column.  Loads outside the image are 0 (FSR_Pass.hlsl:61).
@@ -15,8 +15,16 @@
 
 namespace fsr1 {
 
-constexpr int kRcasHRows = 24;
-constexpr int kRcasHCols = 128 * 4;  // columns per 256-thread workgroup
+#ifndef FSR1_RCASH_ROWS
+#define FSR1_RCASH_ROWS 8
+#endif
+#ifndef FSR1_RCASH_WAVES
+#define FSR1_RCASH_WAVES 2
+#endif
+constexpr int kRcasHRows = FSR1_RCASH_ROWS;   // rows per strip, a multiple of the 4-row ring.  Measured at 4K, us (profiles/ab_r02/r2c9_ab.log): 8 rows 26.7, 16 rows 27.1, 32 rows 31.7; round 1's 24 rows x 4 waves, fully unrolled: 31.0
+constexpr int kRcasHWaves = FSR1_RCASH_WAVES; // waves per workgroup, side by side: the F kernel's shape (fsr1_rcas_kernel.h)
+constexpr int kRcasHThreads = 64 * kRcasHWaves;
+constexpr int kRcasHCols = 128 * kRcasHWaves;  // columns per workgroup
 constexpr int kShr1 = 0x138, kShl1 = 0x130;
 
 namespace {
@@ -30,7 +38,7 @@ __device__ __forceinline__ half2_t dpp2(half2_t keep, half2_t v) {
 
 // OPTS = false: plain pass, flags compiled out.
 template <bool OPTS>
-__global__ void __launch_bounds__(kThreads) rcas_h_kernel(const RcasArgs a) {
+__global__ void __launch_bounds__(kRcasHThreads) rcas_h_kernel(const RcasArgs a) {
   const uint32_t flags = OPTS ? a.flags : 0u;
   const bool stream = (a.flags & FSR1_FLAG_OUTPUT_STREAMING) != 0;
   const int tiles_per_frame = a.tiles_x * a.tiles_y;
@@ -86,13 +94,19 @@ __global__ void __launch_bounds__(kThreads) rcas_h_kernel(const RcasArgs a) {
   const half_t sharp1 = __builtin_bit_cast(half_t, (u16)(a.con[1] & 0xffffu));
   const half2_t one = s2(1.0f);
 
+  static_assert(kRcasHRows % kRing == 0, "strips are a multiple of the ring tall");
+  // the row loop is unrolled by the ring (static ring indices) and rolled beyond that, so the body stays inside the
+  // instruction cache (24 fully unrolled rows were 44 KB of code)
+#pragma unroll 1
+  for (int r0 = 0; r0 < kRcasHRows; r0 += kRing)
 #pragma unroll
-  for (int r = 0; r < kRcasHRows; ++r) {
+  for (int k = 0; k < kRing; ++k) {
+    const int r = r0 + k;
     const int y = y0 + r;
-    load(y + kAhead, q[(r + kAhead) % kRing], g[(r + kAhead) % kRing]);
-    const soa_t& e = q[r % kRing];
-    const soa_t& eh = g[r % kRing];
-    const soa_t& h = q[(r + 1) % kRing];
+    load(y + kAhead, q[(k + kAhead) % kRing], g[(k + kAhead) % kRing]);
+    const soa_t& e = q[k % kRing];
+    const soa_t& eh = g[k % kRing];
+    const soa_t& h = q[(k + 1) % kRing];
     const soa_t& b = prev;
     // d = (left neighbour's right pixel, own left pixel) ; f = (own right pixel, right neighbour's left pixel)
     const half2_t nlR = dpp2<kShr1>(eh.r, e.r), nlG = dpp2<kShr1>(eh.g, e.g), nlB = dpp2<kShr1>(eh.b, e.b);
@@ -123,7 +137,7 @@ void rcas_h_geometry(int width, int height, int* tiles_x, int* tiles_y) {
 hipError_t rcas_h_launch(const RcasArgs& a0, hipStream_t stream) {
   RcasArgs a = a0;
   rcas_h_geometry(a.in.width, a.in.height, &a.tiles_x, &a.tiles_y);  // its own strip shape (two pixels per lane)
-  const dim3 grid((unsigned)(a.tiles_x * a.tiles_y * a.frames)), block(kThreads);
+  const dim3 grid((unsigned)(a.tiles_x * a.tiles_y * a.frames)), block(kRcasHThreads);
   const bool opts = (a.flags & (FSR1_FLAG_RCAS_DENOISE | FSR1_FLAG_RCAS_PASSTHROUGH_ALPHA | FSR1_FLAG_HDR_SQUARE)) != 0;
   if (opts) hipLaunchKernelGGL(rcas_h_kernel<true>, grid, block, 0, stream, a);
   else hipLaunchKernelGGL(rcas_h_kernel<false>, grid, block, 0, stream, a);
