@@ -1,29 +1,31 @@
 // EASU — edge adaptive spatial upsampling (FsrEasuF, ffx-fsr/ffx_fsr1.h:315-437) for gfx950.
 //
-// One 256-thread workgroup produces a 64x16 output tile:
+// One 256-thread workgroup produces a 64x16 output tile (arithmetic: include/fsr1_device_easu.hpp):
 //   phase 1  the tile's input footprint (every texel any of its 12-tap windows can touch, with the
 //            sampler's clamp-to-edge already applied) is read from HBM once, coalesced, converted to
-//            fp32 once per *input* texel and parked in LDS as (R,G,B,luma);
-//   phase 2  everything FsrEasuF recomputes per output pixel but that depends on the input only is
-//            evaluated once per footprint texel: the direction/length terms of FsrEasuSetF
-//            (:295-313: dirX, dirY, lenX^2, lenY^2 of the '+' neighbourhood) and the min/max of the
-//            2x2 block used by the dering clamp (:416-419);
-//   phase 3  each lane walks 4 output pixels of its column: bilinear accumulation of the analysis
-//            in the reference's order, kernel shaping, 12 taps from LDS, dering clamp, one
-//            row-contiguous store per wave.
+//            fp32 once per *input* texel and parked in LDS as (R,G,B,luma); addresses are a scalar row
+//            base plus a 32-bit lane offset, tiles inside the image take a loop without clamps;
+//   phase 2  the direction/length terms of FsrEasuSetF (:295-313: dirX, dirY, lenX^2, lenY^2 of the '+'
+//            neighbourhood) — what FsrEasuF recomputes per output pixel although it depends on the input
+//            only — once per footprint texel that some pixel reads as f/g/j/k.  32 B of LDS per texel;
+//   phase 3  generic: each lane walks 4 output pixels of its column; exact 2x: each lane owns the 2x2 output
+//            quad that shares one 12-tap window.  Bilinear accumulation of the analysis in the reference's
+//            order, kernel shaping, 12 taps from LDS, dering clamp against bounds taken from the four
+//            texels f g j k (once per quad in the exact-2x variant), store.
 //
-// MI355X cost model that shaped phase 3 (tools/ubench/ubench2.hip, measured): v_fma/v_mul/v_add_f32
-// issue at ~2.4 cycles per wave64 instruction, while v_min/v_max/v_cvt/v_fma_mix and every packed
+// MI355X cost model that shaped it (tools/ubench/ubench2.hip, measured): v_fma/v_mul/v_add_f32
+// issue at ~2.4 cycles per wave64 instruction, while v_min/v_max/v_cvt/v_fma_mix, integer and every packed
 // (v_pk_*) instruction take ~4.3 and v_rcp/v_rsq ~8.5.  So: fp32 texels in LDS (no per-tap
 // conversions), plain v_fma_f32 everywhere, the window clip done by the free `clamp` modifier
-// instead of v_min_f32, min/max hoisted to phase 2.
+// instead of v_min_f32, and as few 4-cycle instructions in staging as possible (DESIGN.md section 3.1 has the
+// per-phase instruction budget: 944 per wave, 89 % of them the per-pixel filter itself).
 //
 // Numerics: arithmetic is fp32 (FsrEasuF), storage is the image format.  Everything up to and
 // including the `dirR < 1/32768` decision is evaluated in the reference's exact operation order
 // (no contraction): that decision and floor() are the only discontinuities of the filter, so
 // they must see bit-identical inputs.  With EXACT the rest follows the reference order as well and
 // the result is bit-identical to the CPU-evaluated FsrEasuF; without it the continuous remainder
-// is re-associated (see easu_pixel in fsr1_device_easu.hpp), which moves the fp32 result by ~1e-6 relative.
+// is re-associated (easu_filter in fsr1_device_easu.hpp), which moves the fp32 result by ~1e-6 relative.
 #include "fsr1_easu_kernel.h"
 
 namespace fsr1 {

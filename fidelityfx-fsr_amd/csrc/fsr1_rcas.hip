@@ -1,8 +1,8 @@
 // RCAS — robust contrast adaptive sharpening (FsrRcasF, ffx-fsr/ffx_fsr1.h:684-769) for gfx950.
 //
-// 8 B read + 8 B written per pixel (RGBA16F) against ~100 VALU instructions: on MI355X the pass sits
-// right at the HBM/VALU balance point, so the kernel is built to touch every input byte once, to move
-// 16 bytes per lane per memory instruction, and to spend no instruction on staging:
+// 8 B read + 8 B written per pixel (RGBA16F) against 80 VALU instructions: on MI355X the pass moves its bytes
+// at the chip's copy rate, so the kernel is built to touch every input byte as few
+// times as it can, to move 16 bytes per lane per memory instruction, and to spend no instruction on staging:
 //   * no LDS, no barrier: a wave owns a 128-column x 16-row strip and streams down it, a lane owning TWO
 //     adjacent columns (one 16-byte load and one 16-byte store per row);
 //   * vertical neighbours (b above, h below) are the lane's own previous/next rows kept in registers;
@@ -10,7 +10,11 @@
 //     facing pixels, fetched in fp32 with DPP wave shifts (v_mov_b32_dpp wave_shr:1 / wave_shl:1);
 //   * lanes 0 and 63 additionally load the one texel left / right of the strip, which the DPP move
 //     leaves in place for exactly those lanes (an invalid DPP source keeps the old destination);
-//   * every texel is converted to fp32 once; loads run kAhead rows ahead of the arithmetic;
+//   * every texel is converted to fp32 once; loads run ahead of the arithmetic through a register ring;
+//   * row addresses are a scalar 64-bit row base plus a 32-bit lane offset; the ring min/max are single
+//     v_min3 / v_max3 instructions (include/fsr1_device_rcas.hpp);
+//   * the output — the pipeline's last image — is stored non-temporally (FSR1_FLAG_OUTPUT_STREAMING), so it
+//     does not displace the intermediary EASU just left in the Infinity Cache;
 //   * strips that lie wholly inside the image (all but the image's border strips) run a branch-free body:
 //     one basic block per strip, no per-lane predicates, no zero fills;
 //   * texels outside the image are 0 (the D3D `Load` rule of the reference's callback, FSR_Pass.hlsl:45,61).
