@@ -71,6 +71,30 @@ def assert_f_class(gpu, want_f32, what):
     assert not np.isnan(g).any(), what + ": NaN in the output"
 
 
+def _mono(h16):
+    """binary16 bit patterns (int16 view) -> integers monotone in the value (sign-magnitude unfolded), on the GPU"""
+    i = h16.view(torch.int16).to(torch.int32)
+    return torch.where(i < 0, -(i & 0x7FFF), i)
+
+
+def gpu_assert_exact16(got16, want_f32, what):
+    """assert_exact16 evaluated on the device: `want` is uploaded as binary32 and rounded RTNE there (same rounding as numpy)"""
+    want16 = torch.from_numpy(np.ascontiguousarray(want_f32, np.float32)).cuda().to(torch.float16)
+    bad = got16.view(torch.int16) != want16.view(torch.int16)
+    n = int(bad.sum())
+    assert n == 0, "%s: %d of %d binary16 values differ (first at %s)" % (what, n, bad.numel(), torch.nonzero(bad)[:3].tolist())
+
+
+def gpu_assert_f_class(got16, want_f32, what):
+    want16 = torch.from_numpy(np.ascontiguousarray(want_f32, np.float32)).cuda().to(torch.float16)
+    d = (_mono(got16) - _mono(want16)).abs()
+    mx = int(d.max())
+    assert mx <= ULP_TOL, "%s: max %d binary16 ULP (tolerance %d)" % (what, mx, ULP_TOL)
+    frac = float((d == 0).float().mean())
+    assert frac >= MIN_EXACT_FRACTION, "%s: only %.4f of the values bit-equal" % (what, frac)
+    assert not bool(torch.isnan(got16).any()), what + ": NaN in the output"
+
+
 SHAPES = {
     "540p_to_1080p": (960, 540, 1920, 1080),     # configs[0] shape
     "1080p_to_4k": (1920, 1080, 3840, 2160),     # configs[1], [3]
@@ -205,15 +229,14 @@ def _batch(fsr, checker, name, n, pipelines):
             fsr.easu_rcas_fused(src, fus, easu_con=con, rcas_con=rc, flags=fl)
             assert torch.equal(outs[exact].view(torch.int16), fus.view(torch.int16)), tag + ": fused batch differs from the two-pass batch"
             del fus
-    for f in range(n):  # every frame of the batch, whole; the reference's EASU is evaluated once per frame
+    for f in range(n):  # every frame of the batch, whole; the reference's EASU is evaluated once per frame, compared on the device
         want_mid = checker.easu_f(host(src[f]).astype(np.float32), ow, oh, con)
         for exact in (True, False):
             tag = "%s x%d %s frame %d" % (name, n, "EXACT" if exact else "F", f)
-            got_mid = host(mids[exact][f])
-            (assert_exact16 if exact else assert_f_class)(got_mid, want_mid, tag + " easu")
+            (gpu_assert_exact16 if exact else gpu_assert_f_class)(mids[exact][f], want_mid, tag + " easu")
             if exact or f % 4 == 0:  # RCAS is judged on the GPU's own intermediary: EXACT on every frame, F on every fourth
-                want = checker.rcas_f(got_mid.astype(np.float32), rc)
-                (assert_exact16 if exact else assert_f_class)(host(outs[exact][f]), want, tag + " rcas")
+                want = checker.rcas_f(host(mids[exact][f]).astype(np.float32), rc)
+                (gpu_assert_exact16 if exact else gpu_assert_f_class)(outs[exact][f], want, tag + " rcas")
 
 
 def test_batch_1440p_to_4k_x8_all_frames(fsr, checker):
