@@ -193,6 +193,41 @@ def rcas(src, dst, con=None, sharpness=0.25, flags=0, stream=None, stages=None):
     return dst
 
 
+def easu_band(src, dst_band, con, origin=(0, 0), flags=0, stream=None):
+    """dst_band = the window of EASU(src) whose pixel (0, 0) is output pixel `origin` = (x, y) of the full image `con` describes."""
+    i, o = image_of(src), image_of(dst_band)
+    con = _con(con, 16)
+    _lib.check(_lib.load().fsr1_easu_dispatch_band(ctypes.byref(i), ctypes.byref(o), _u32p(con), flags, int(origin[0]), int(origin[1]), _stream_ptr(stream)))
+    return dst_band
+
+
+def rcas_band(src_band, dst_band, con=None, sharpness=0.25, rows_above=0, rows_below=0, flags=0, stream=None):
+    """RCAS on a band: `src_band` is a view of the band's own rows inside a larger tensor; rows_above / rows_below = 1 when the
+    row just above / below the view exists in that tensor and belongs to the image."""
+    i, o = image_of(src_band), image_of(dst_band)
+    con = _con(FsrRcasCon(sharpness) if con is None else con, 4)
+    _lib.check(_lib.load().fsr1_rcas_dispatch_band(ctypes.byref(i), ctypes.byref(o), _u32p(con), flags, int(rows_above), int(rows_below), _stream_ptr(stream)))
+    return dst_band
+
+
+def upscale_band(src, dst_band, out_size, band, mid=None, sharpness=0.25, flags=0, stream=None):
+    """EASU + RCAS for output rows [band[0], band[1]) of an `out_size` = (width, height) upscale of `src`, written to `dst_band`
+    (band[1] - band[0] rows): what one GPU does when a single frame is split into row bands.  `mid` (optional)
+    is a scratch tensor of at least band rows + 2; returns dst_band."""
+    import torch
+    ow, oh = out_size
+    y0, y1 = band
+    i = image_of(src)
+    con = FsrEasuCon(i.width, i.height, i.width, i.height, ow, oh)
+    m0, m1 = max(y0 - 1, 0), min(y1 + 1, oh)  # EASU rows the band's RCAS taps read
+    if mid is None:
+        mid = torch.empty(m1 - m0, ow, 4, dtype=dst_band.dtype, device=dst_band.device)
+    mid = mid[:m1 - m0]
+    easu_band(src, mid, con, origin=(0, m0), flags=flags, stream=stream)
+    rcas_band(mid[y0 - m0:y0 - m0 + (y1 - y0)], dst_band, sharpness=sharpness, rows_above=int(m0 < y0), rows_below=int(m1 > y1), flags=flags, stream=stream)
+    return dst_band
+
+
 def easu_rcas_fused(src, dst, easu_con=None, rcas_con=None, sharpness=0.25, flags=0, stream=None, stages=None):
     """dst = RCAS(EASU(src)) in one launch (intermediate kept in LDS).  stages: optional ColorStages fused in."""
     i, o = image_of(src), image_of(dst)

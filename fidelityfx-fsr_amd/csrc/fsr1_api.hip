@@ -135,14 +135,14 @@ static bool overlaps(const fsr1_image* a, const ImageView& va, const fsr1_image*
 // `apron` = 1 for the fused kernel, whose tiles compute one extra pixel on each side (clipped to the image).
 // Exactness matters: LDS per workgroup decides how many workgroups a CU holds (35x11 texels x 48 B lets 8 of them
 // in at 2x; two texels of slack per axis would leave 6).
-static int footprint_extent(int out_size, int tile, int apron, float scale, float bias) {
+static int footprint_extent(int out_size, int tile, int apron, float scale, float bias, int origin = 0) {
   if (!(scale > 0.0f) || !std::isfinite(scale) || !std::isfinite(bias)) return -1;
   if ((double)(tile + 2 * apron) * (double)scale > 4096.0) return -1;
   const int tiles = (out_size + tile - 1) / tile;
   int best = 0;
   for (int t = 0; t < tiles; ++t) {
-    const int o0 = std::max(t * tile - apron, 0);
-    const int ol = std::min(t * tile + tile - 1 + apron, out_size - 1);
+    const int o0 = std::max(t * tile - apron, 0) + origin;  // `origin`: the image is a band of a larger output image
+    const int ol = std::min(t * tile + tile - 1 + apron, out_size - 1) + origin;
     const float p0 = (float)o0 * scale, pl = (float)ol * scale;  // two roundings each, as on the device
     const int f0 = (int)std::floor(p0 + bias), fl = (int)std::floor(pl + bias);
     best = std::max(best, fl - f0 + 4);
@@ -233,8 +233,26 @@ int fsr1_easu_dispatch(const fsr1_image* in, const fsr1_image* out, const uint32
   return fsr1_easu_dispatch_ex(in, out, con, flags, nullptr, stream);
 }
 
+static int easu_dispatch_impl(const fsr1_image* in, const fsr1_image* out, const uint32_t con[16], uint32_t flags,
+                              const fsr1_color_stages* stages, int origin_x, int origin_y, void* stream);
+
 int fsr1_easu_dispatch_ex(const fsr1_image* in, const fsr1_image* out, const uint32_t con[16], uint32_t flags,
                           const fsr1_color_stages* stages, void* stream) {
+  return easu_dispatch_impl(in, out, con, flags, stages, 0, 0, stream);
+}
+
+// A band of the output image (a single frame split over GPUs as row bands, zero exchange): `out` holds output
+// pixels [origin_x, origin_x + out->width) x [origin_y, origin_y + out->height) of the image `con` was set up for.
+int fsr1_easu_dispatch_band(const fsr1_image* in, const fsr1_image* out, const uint32_t con[16], uint32_t flags, int32_t origin_x,
+                            int32_t origin_y, void* stream) {
+  if (origin_x < 0 || origin_y < 0 || origin_x > (1 << 20) || origin_y > (1 << 20))
+    return fail(FSR1_ERR_INVALID_ARGUMENT, "easu band: origin (%d, %d) out of range", origin_x, origin_y);
+  if (flags & FSR1_FLAG_MATH_PACKED_FP16) return fail(FSR1_ERR_UNSUPPORTED, "easu band: bands run with the F (binary32) arithmetic");
+  return easu_dispatch_impl(in, out, con, flags, nullptr, origin_x, origin_y, stream);
+}
+
+static int easu_dispatch_impl(const fsr1_image* in, const fsr1_image* out, const uint32_t con[16], uint32_t flags,
+                              const fsr1_color_stages* stages, int origin_x, int origin_y, void* stream) {
   const Range range("easu", in, out);
   EasuArgs a;
   int rc;
@@ -254,8 +272,10 @@ int fsr1_easu_dispatch_ex(const fsr1_image* in, const fsr1_image* out, const uin
   memcpy(&sy, &con[1], 4);
   memcpy(&bx, &con[2], 4);
   memcpy(&by, &con[3], 4);
-  a.fp_w = footprint_extent(out->width, kTileW, 0, sx, bx);
-  a.fp_h = footprint_extent(out->height, kTileH, 0, sy, by);
+  a.origin_x = origin_x;
+  a.origin_y = origin_y;
+  a.fp_w = footprint_extent(out->width, kTileW, 0, sx, bx, origin_x);
+  a.fp_h = footprint_extent(out->height, kTileH, 0, sy, by, origin_y);
   if (a.fp_w < 0 || a.fp_h < 0) return fail(FSR1_ERR_INVALID_ARGUMENT, "easu: scale constants con0.xy = (%g, %g) are not usable", sx, sy);
   if (easu_lds_bytes(in->format, a.fp_w, a.fp_h) > 160 * 1024)
     return fail(FSR1_ERR_UNSUPPORTED, "easu: input/output ratio (%g, %g) needs a %dx%d texel footprint per tile, beyond the LDS budget "
@@ -270,7 +290,7 @@ int fsr1_easu_dispatch_ex(const fsr1_image* in, const fsr1_image* out, const uin
   // out = 2 * in — takes the variant whose lanes own 2x2 output quads; its tiles are shifted by one pixel, hence one
   // more tile per axis when the size is a multiple of the tile, and the footprint of a tile is 64/2+3 x 16/2+3 texels.
   const bool s2 = con[0] == 0x3f000000u && con[1] == 0x3f000000u && con[2] == 0xbe800000u && con[3] == 0xbe800000u &&
-                  !(flags & FSR1_FLAG_NO_FAST_PATHS) && !a.color.stages && kTileH % 16 == 0;
+                  !(flags & FSR1_FLAG_NO_FAST_PATHS) && !a.color.stages && kTileH % 16 == 0 && !((origin_x | origin_y) & 1);
   if (s2) {
     a.tiles_x = (out->width + 1 + kTileW - 1) / kTileW;
     a.tiles_y = (out->height + 1 + kTileH - 1) / kTileH;
@@ -295,8 +315,26 @@ int fsr1_rcas_dispatch(const fsr1_image* in, const fsr1_image* out, const uint32
   return fsr1_rcas_dispatch_ex(in, out, con, flags, nullptr, stream);
 }
 
+static int rcas_dispatch_impl(const fsr1_image* in, const fsr1_image* out, const uint32_t con[4], uint32_t flags,
+                              const fsr1_color_stages* stages, int rows_above, int rows_below, void* stream);
+
 int fsr1_rcas_dispatch_ex(const fsr1_image* in, const fsr1_image* out, const uint32_t con[4], uint32_t flags,
                           const fsr1_color_stages* stages, void* stream) {
+  return rcas_dispatch_impl(in, out, con, flags, stages, 0, 0, stream);
+}
+
+// RCAS on a band of a larger image: `in` describes the band's own rows, and rows_above / rows_below (0 or 1) say whether the
+// row just above `in`'s first row / just below its last row exists IN MEMORY (same pitch) as part of the larger image —
+// those taps are then read instead of being 0.  Columns are the full image width.
+int fsr1_rcas_dispatch_band(const fsr1_image* in, const fsr1_image* out, const uint32_t con[4], uint32_t flags, int32_t rows_above,
+                            int32_t rows_below, void* stream) {
+  if ((rows_above | rows_below) & ~1) return fail(FSR1_ERR_INVALID_ARGUMENT, "rcas band: rows_above / rows_below must be 0 or 1");
+  if (flags & FSR1_FLAG_MATH_PACKED_FP16) return fail(FSR1_ERR_UNSUPPORTED, "rcas band: bands run with the F (binary32) arithmetic");
+  return rcas_dispatch_impl(in, out, con, flags, nullptr, rows_above, rows_below, stream);
+}
+
+static int rcas_dispatch_impl(const fsr1_image* in, const fsr1_image* out, const uint32_t con[4], uint32_t flags,
+                              const fsr1_color_stages* stages, int rows_above, int rows_below, void* stream) {
   const Range range("rcas", in, out);
   RcasArgs a;
   int rc;
@@ -311,12 +349,21 @@ int fsr1_rcas_dispatch_ex(const fsr1_image* in, const fsr1_image* out, const uin
   if (in->width != out->width || in->height != out->height || in->frames != out->frames)
     return fail(FSR1_ERR_INVALID_ARGUMENT, "rcas: input %dx%dx%d and output %dx%dx%d extents differ", in->width, in->height,
                 in->frames, out->width, out->height, out->frames);
-  if (overlaps(in, a.in, out, a.out)) return fail(FSR1_ERR_INVALID_ARGUMENT, "rcas: input and output overlap (RCAS cannot run in place)");
+  {
+    fsr1_image in_ext = *in;  // what the pass reads: the band plus the neighbouring rows it was told exist
+    ImageView v_ext = a.in;
+    in_ext.height += rows_above + rows_below;
+    v_ext.base -= (long long)rows_above * a.in.pitch;
+    if (overlaps(&in_ext, v_ext, out, a.out)) return fail(FSR1_ERR_INVALID_ARGUMENT, "rcas: input and output overlap (RCAS cannot run in place)");
+  }
+  if ((rows_above || rows_below) && in->frames != 1) return fail(FSR1_ERR_UNSUPPORTED, "rcas band: one frame per dispatch");
   memcpy(a.con, con, sizeof a.con);
   rcas_geometry(out->width, out->height, out->frames, &a.tiles_x, &a.tiles_y, &a.rows);
   a.frames = out->frames;
   if ((rc = check_grid("rcas", a.tiles_x, a.tiles_y, a.frames))) return rc;
   a.flags = resolve_output_policy(flags, true);
+  a.rows_above = rows_above;
+  a.rows_below = rows_below;
   hipError_t e;
   if (flags & FSR1_FLAG_MATH_PACKED_FP16) {
     if (in->format != FSR1_FORMAT_RGBA16F) return fail(FSR1_ERR_UNSUPPORTED, "rcas: packed-fp16 math needs RGBA16F images");

@@ -38,6 +38,7 @@ struct EasuArgs {
   int tiles_x, tiles_y, frames;
   int fp_w, fp_h;  // LDS footprint capacity (texels) per tile, >= the largest footprint of any tile
   uint32_t flags;
+  int origin_x, origin_y;  // `out` is a window of the full output image: its pixel (0, 0) is output pixel (origin_x, origin_y)
   ColorArgs color;
 };
 
@@ -47,6 +48,7 @@ struct RcasArgs {
   int tiles_x, tiles_y, frames;
   int rows;  // rows per strip (a multiple of the kernel's row ring), chosen by the launcher
   uint32_t flags;
+  int rows_above, rows_below;  // 1: the image continues in memory above row 0 / below the last row (a band of a larger image): those taps are read, not 0
   ColorArgs color;
 };
 

@@ -41,7 +41,7 @@ __global__ void __launch_bounds__(kThreads) easu_kernel(const EasuArgs a) {
     //      (qx, qy) shares the texel f = (32 tx - 1 + qx, 8 ty - 1 + qy), so the footprint starts two texels before ----
     static_assert(!COLOR && kTileW == 64, "the exact-2x variant is built for the plain 64-wide tiles");
     const int ox0 = tx * kTileW - 1, oy0 = ty * kTileH - 1;
-    const int fx0 = tx * (kTileW / 2) - 2, fy0 = ty * (kTileH / 2) - 2;
+    const int fx0 = tx * (kTileW / 2) - 2 + (a.origin_x >> 1), fy0 = ty * (kTileH / 2) - 2 + (a.origin_y >> 1);  // (band origins are even here)
     l.fw = kS2W;
     easu_stage_footprint<FMT, false, EXACT, kS2W, kS2H>(l, a.in, in_frame, fx0, fy0, kS2W, kS2H, tid);
     const int W = a.out.width, H = a.out.height;
@@ -82,10 +82,12 @@ __global__ void __launch_bounds__(kThreads) easu_kernel(const EasuArgs a) {
   // Footprint of this tile: fp(first pixel)-1 .. fp(last pixel)+2 per axis (ffx_fsr1.h:324-342).
   // Same arithmetic as the per-pixel position below, and x -> x*c+b is monotone under rounding.
   const int oxl = min(ox0 + kTileW, a.out.width) - 1, oyl = min(oy0 + kTileH, a.out.height) - 1;
-  const int fx0 = (int)floorf((float)ox0 * c0x + c0z) - 1;
-  const int fy0 = (int)floorf((float)oy0 * c0y + c0w) - 1;
-  const int fw = min((int)floorf((float)oxl * c0x + c0z) + 2 - fx0 + 1, a.fp_w);
-  const int fh = min((int)floorf((float)oyl * c0y + c0w) + 2 - fy0 + 1, a.fp_h);
+  // (a.origin: `out` may be a band of the full output image — positions are those of the full image)
+  const int gx0 = ox0 + a.origin_x, gy0 = oy0 + a.origin_y;
+  const int fx0 = (int)floorf((float)gx0 * c0x + c0z) - 1;
+  const int fy0 = (int)floorf((float)gy0 * c0y + c0w) - 1;
+  const int fw = min((int)floorf((float)(oxl + a.origin_x) * c0x + c0z) + 2 - fx0 + 1, a.fp_w);
+  const int fh = min((int)floorf((float)(oyl + a.origin_y) * c0y + c0w) + 2 - fy0 + 1, a.fp_h);
   l.fw = fw;
   easu_stage_footprint<FMT, COLOR, EXACT>(l, a.in, in_frame, fx0, fy0, fw, fh, tid, &a.color);
 
@@ -94,7 +96,7 @@ __global__ void __launch_bounds__(kThreads) easu_kernel(const EasuArgs a) {
   if (ox >= a.out.width) return;
   char* const out_col = a.out.base + (long long)frame * a.out.frame_stride + (size_t)ox * sizeof(texel_t);
   // :324-326 (x part, shared by this lane's rows)
-  float ppx = (float)ox * c0x + c0z;
+  float ppx = (float)(ox + a.origin_x) * c0x + c0z;
   const float fpx = floorf(ppx);
   ppx -= fpx;
   const int lx = (int)fpx - fx0;  // footprint column of texel 'f'
@@ -107,7 +109,7 @@ __global__ void __launch_bounds__(kThreads) easu_kernel(const EasuArgs a) {
   for (int r = 0; r < kTileH / 4; ++r) {
     const int oy = oy0 + wave * (kTileH / 4) + r;
     if (oy >= a.out.height) break;
-    float ppy = (float)oy * c0y + c0w;
+    float ppy = (float)(oy + a.origin_y) * c0y + c0w;
     const float fpy = floorf(ppy);
     ppy -= fpy;
     const int f_idx = ((int)fpy - fy0) * fw + lx;

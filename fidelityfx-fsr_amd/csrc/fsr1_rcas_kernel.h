@@ -83,7 +83,7 @@ __device__ __forceinline__ void rcas_strip(const RcasArgs& a, int frame, int x0,
     } else {
       r.p0 = Pixel<FMT>::zero();
       r.p1 = Pixel<FMT>::zero();
-      if (y >= 0 && y < H) {  // wave-uniform
+      if (y >= -a.rows_above && y < H + a.rows_below) {  // wave-uniform; a band's neighbouring rows are real texels
         if (ok1) {
           const pair_t pr = *reinterpret_cast<const pair_t*>(in_frame + (long long)y * a.in.pitch + zext(off));
           __builtin_memcpy(&r.p0, &pr, sizeof(texel_t));
@@ -176,7 +176,8 @@ __global__ void __launch_bounds__(kRcasThreads) rcas_kernel(const RcasArgs a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int x0 = tx * kRcasCols + wave * kRcasWaveCols, y0 = ty * a.rows;
   if (x0 >= a.in.width) return;  // whole wave outside (no barriers in this kernel)
-  const bool interior = x0 >= 1 && x0 + kRcasWaveCols + 1 <= a.in.width && y0 >= 1 && y0 + a.rows + 1 <= a.in.height;
+  const bool interior = x0 >= 1 && x0 + kRcasWaveCols + 1 <= a.in.width && y0 >= 1 - a.rows_above && y0 + a.rows + 1 <= a.in.height + a.rows_below &&
+                        y0 + a.rows <= a.in.height;  // (the interior body stores every row of the strip)
 #ifdef FSR1_RCAS_ALTERNATE
   if (interior && (ty & 1)) rcas_strip<FMT, EXACT, OPTS, true, COLOR, FOUT, RING, true>(a, frame, x0, y0, lane);
   else

@@ -200,6 +200,23 @@ int fsr1_easu_rcas_fused_dispatch_ex(const fsr1_image* in, const fsr1_image* out
                                      const uint32_t rcas_con[4], uint32_t flags, const fsr1_color_stages* stages,
                                      void* stream);
 
+/* ----------------------------------------------------------------------------------------------
+ * Row bands of one frame (optional): a single frame split over several GPUs without any
+ * exchange.  Every GPU holds the whole INPUT frame and produces a band of output rows:
+ *   1. fsr1_easu_dispatch_band writes output rows [origin_y - 1, origin_y + rows + 1) (clipped to the image) of
+ *      the EASU result into a band-sized intermediary: `out` is that band, (origin_x, origin_y) the position of its
+ *      pixel (0, 0) in the full output image `con` was set up for (the position arithmetic of ffx_fsr1.h:324-326
+ *      runs on full-image coordinates, so the band is bit-identical to the same rows of a full-frame dispatch);
+ *   2. fsr1_rcas_dispatch_band sharpens the band's own rows: `in` describes them, rows_above / rows_below (0 or 1)
+ *      say that the row just above / below exists in memory (the extra EASU rows of step 1) and is to be read
+ *      instead of being treated as outside the image (= 0).
+ * F arithmetic (default or FSR1_FLAG_MATH_EXACT), one frame per dispatch for the RCAS band.
+ * ---------------------------------------------------------------------------------------------- */
+int fsr1_easu_dispatch_band(const fsr1_image* in, const fsr1_image* out, const uint32_t con[16], uint32_t flags,
+                            int32_t origin_x, int32_t origin_y, void* stream);
+int fsr1_rcas_dispatch_band(const fsr1_image* in, const fsr1_image* out, const uint32_t con[4], uint32_t flags,
+                            int32_t rows_above, int32_t rows_below, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * FSR_Filter::Upscale (sample/src/DX12/FSR_Filter.cpp:101-141) as one call.
  * ---------------------------------------------------------------------------------------------- */

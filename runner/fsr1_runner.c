@@ -14,7 +14,11 @@
  *
  *   fsr1_runner [--gpus N] [--frames F] [--in WxH] [--out WxH] [--steps K] [--warmup W]
  *               [--pipeline two-pass|fused|easu|auto] [--math f|exact|h] [--sharpness STOPS] [--hdr]
- *               [--stages BITS] [--grain AMOUNT] [--ring R]
+ *               [--stages BITS] [--grain AMOUNT] [--ring R] [--bands]
+ *
+ * --bands: strong scaling of ONE frame stream instead of weak scaling over frames — every GPU holds the whole
+ * input frame and produces one band of output rows (fsr1_easu_dispatch_band on the band plus a row either side, then
+ * fsr1_rcas_dispatch_band); still no image byte crosses a link.
  *
  * --stages fuses colour stages into the passes (FSR1_COLOR_* bits of fsr1_hip.h: 1 FsrSrtmF on the input, 2 FsrLfgaF
  * film grain, 4 FsrSrtmInvF, 8 / 16 FsrTepdC8F / FsrTepdC10F dither) — what the sample's colour pass does around the
@@ -41,6 +45,7 @@ typedef struct {
   uint32_t stages; /* FSR1_COLOR_* */
   float grain;
   int ring; /* frame sets to rotate over; 0 = enough to exceed the 256 MiB Infinity Cache */
+  int bands; /* 1: one frame per step, split into row bands over the GPUs */
 } options_t;
 
 /* A rank that fails must not leave the others blocked in the collective: every rank reaches this barrier, failed or
@@ -141,6 +146,61 @@ static void shard(int total, int rank, int world, int* begin, int* end) {
   *end = *begin + q + (rank < r ? 1 : 0);
 }
 
+/* --bands: this GPU's band of every frame.  Band boundaries are even rows (the exact-2x kernel's quads). */
+static int worker_body_bands(worker_t* w) {
+  const options_t* o = w->opt;
+  hipStream_t stream = w->stream;
+  int y0 = (int)((long long)o->out_h * w->rank / o->gpus) & ~1, y1 = w->rank + 1 == o->gpus ? o->out_h : ((int)((long long)o->out_h * (w->rank + 1) / o->gpus) & ~1);
+  const int rows = y1 - y0;
+  const int m0 = y0 > 0 ? y0 - 1 : 0, m1 = y1 < o->out_h ? y1 + 1 : o->out_h;  /* EASU rows the band's RCAS taps read */
+  const size_t in_frame = (size_t)o->in_w * o->in_h * 8, pitch = (size_t)o->out_w * 8;
+  int ring = o->ring > 0 ? o->ring : (int)((320u * 1024u * 1024u + in_frame - 1) / in_frame);
+  if (ring < 2) ring = 2;
+  if (ring > 16) ring = 16;
+  w->ring = ring;
+  if (rows > 0) {
+    HIP_OK(w, hipMalloc(&w->d_in, in_frame * ring));
+    HIP_OK(w, hipMalloc(&w->d_mid, pitch * (size_t)(m1 - m0)));
+    HIP_OK(w, hipMalloc(&w->d_out, pitch * (size_t)rows * ring));
+    uint16_t* host = (uint16_t*)malloc(in_frame);
+    if (!host) { snprintf(w->error, sizeof w->error, "out of host memory"); w->status = -1; return -1; }
+    for (int s = 0; s < ring; ++s) {
+      synth_frame(host, o->in_w, o->in_h, 1000 * s);  /* every GPU holds the whole frame */
+      hipError_t e = hipMemcpy((char*)w->d_in + in_frame * s, host, in_frame, hipMemcpyHostToDevice);
+      if (e != hipSuccess) { free(host); HIP_OK(w, e); }
+    }
+    free(host);
+  }
+  uint32_t easu[16], rcas[4];
+  FsrEasuCon(easu, easu + 4, easu + 8, easu + 12, (float)o->in_w, (float)o->in_h, (float)o->in_w, (float)o->in_h, (float)o->out_w, (float)o->out_h);
+  FsrRcasCon(rcas, o->sharpness);
+  HIP_OK(w, hipEventCreate(&w->ev0));
+  HIP_OK(w, hipEventCreate(&w->ev1));
+  float ms = 0.f;
+  if (rows > 0) {
+    for (int i = -o->warmup; i < o->steps; ++i) {
+      if (i == 0) HIP_OK(w, hipEventRecord(w->ev0, stream));
+      const size_t s = (size_t)((i + o->warmup) % ring);
+      fsr1_image in = {(char*)w->d_in + in_frame * s, o->in_w, o->in_h, FSR1_FORMAT_RGBA16F, 1, 0, 0};
+      fsr1_image mid = {w->d_mid, o->out_w, m1 - m0, FSR1_FORMAT_RGBA16F, 1, 0, 0};
+      fsr1_image mid_band = {(char*)w->d_mid + pitch * (size_t)(y0 - m0), o->out_w, rows, FSR1_FORMAT_RGBA16F, 1, 0, 0};
+      fsr1_image out = {(char*)w->d_out + pitch * (size_t)rows * s, o->out_w, rows, FSR1_FORMAT_RGBA16F, 1, 0, 0};
+      FSR_OK(w, fsr1_easu_dispatch_band(&in, &mid, easu, o->math, 0, m0, stream));
+      FSR_OK(w, fsr1_rcas_dispatch_band(&mid_band, &out, rcas, o->math | (o->hdr ? FSR1_FLAG_HDR_SQUARE : 0u), m0 < y0, m1 > y1, stream));
+    }
+    HIP_OK(w, hipEventRecord(w->ev1, stream));
+    HIP_OK(w, hipEventSynchronize(w->ev1));
+    HIP_OK(w, hipEventElapsedTime(&ms, w->ev0, w->ev1));
+  }
+  w->counters[0] = (uint64_t)o->steps;  /* frames this rank took part in */
+  w->counters[1] = (uint64_t)o->steps * (uint64_t)o->out_w * (uint64_t)rows;
+  w->counters[2] = (uint64_t)((double)ms * 1e6);
+  HIP_OK(w, hipMalloc((void**)&w->d_send, sizeof w->counters));
+  HIP_OK(w, hipMalloc((void**)&w->d_recv, sizeof w->counters * o->gpus));
+  HIP_OK(w, hipMemcpyAsync(w->d_send, w->counters, sizeof w->counters, hipMemcpyHostToDevice, stream));
+  return 0;
+}
+
 static int worker_body(worker_t* w) {
   const options_t* o = w->opt;
   int f0, f1;
@@ -150,6 +210,7 @@ static int worker_body(worker_t* w) {
   HIP_OK(w, hipStreamCreate(&w->stream));
   hipStream_t stream = w->stream;
 
+  if (o->bands) return worker_body_bands(w);
   const int needs_mid = o->pipeline == 0 || o->pipeline == 3;
   const size_t in_frame = (size_t)o->in_w * o->in_h * 8, out_frame = (size_t)o->out_w * o->out_h * 8;
   const size_t set_bytes = (in_frame + out_frame * (needs_mid ? 2 : 1)) * (size_t)(nf > 0 ? nf : 1);
@@ -258,16 +319,18 @@ static void usage(void) {
        "                   [--pipeline two-pass|fused|easu|auto] [--math f|exact|h] [--sharpness STOPS] [--hdr]\n"
        "                   [--stages BITS] [--grain AMOUNT]   (colour stages: 1 SRTM, 2 grain, 4 SRTM inverse, 8/16 TEPD 8/10-bit)\n"
        "                   [--ring R]   (frame sets to rotate over; default: enough to exceed the 256 MiB Infinity Cache)\n"
+       "                   [--bands]    (one frame stream split into row bands over the GPUs instead of frames per GPU)\n"
        "defaults: 1 GPU, 1 frame per GPU, 1920x1080 -> 3840x2160, 100 steps, 10 warmup, two-pass, f, 0.25 stops");
 }
 
 int main(int argc, char** argv) {
-  options_t o = {1, 0, 1920, 1080, 3840, 2160, 100, 10, 0, 0, 0u, 0.25f, 0u, 0.25f, 0};
+  options_t o = {1, 0, 1920, 1080, 3840, 2160, 100, 10, 0, 0, 0u, 0.25f, 0u, 0.25f, 0, 0};
   for (int i = 1; i < argc; ++i) {
     const char* a = argv[i];
     const char* v = i + 1 < argc ? argv[i + 1] : NULL;
     if (!strcmp(a, "--help") || !strcmp(a, "-h")) { usage(); return 0; }
     else if (!strcmp(a, "--hdr")) o.hdr = 1;
+    else if (!strcmp(a, "--bands")) o.bands = 1;
     else if (!v) { fprintf(stderr, "missing value for %s\n", a); return 2; }
     else if (!strcmp(a, "--gpus")) { o.gpus = atoi(v); ++i; }
     else if (!strcmp(a, "--frames")) { o.frames = atoi(v); ++i; }
@@ -296,6 +359,10 @@ int main(int argc, char** argv) {
   const int visible = fsr1_device_count();
   if (visible < 0) { fprintf(stderr, "cannot enumerate GPUs: %s\n", fsr1_last_error()); return 1; }
   if (visible < o.gpus) { fprintf(stderr, "need %d GPUs, %d visible\n", o.gpus, visible); return 1; }
+  if (o.bands && (o.pipeline != 0 || o.stages || (o.math & FSR1_FLAG_MATH_PACKED_FP16))) {
+    fprintf(stderr, "--bands runs the two F dispatches without colour stages\n");
+    return 2;
+  }
   if ((o.math & FSR1_FLAG_MATH_PACKED_FP16) && o.stages) {
     fprintf(stderr, "--math h (FsrEasuH / FsrRcasH) runs without colour stages\n");
     return 2;
@@ -324,7 +391,8 @@ int main(int argc, char** argv) {
   if (!rc) {
     uint64_t frames = 0, pixels = 0, max_ns = 0;
     for (int i = 0; i < o.gpus; ++i) {
-      frames += gathered[3 * i]; pixels += gathered[3 * i + 1];
+      frames = o.bands ? gathered[3 * i] : frames + gathered[3 * i];  /* --bands: every rank works on the same frames */
+      pixels += gathered[3 * i + 1];
       if (gathered[3 * i + 2] > max_ns) max_ns = gathered[3 * i + 2];
     }
     const double sec = (double)max_ns * 1e-9;
@@ -332,10 +400,10 @@ int main(int argc, char** argv) {
     const double bytes = (double)frames * (double)(o.pipeline == 0 ? in_b + 3 * out_b : in_b + out_b);
     printf("{\"metric\": \"upscaled megapixels/sec\", \"value\": %.1f, \"unit\": \"Mpix/s\", \"n_gpus\": %d, \"frames\": %llu, "
            "\"steps\": %d, \"seconds\": %.6f, \"in\": \"%dx%d\", \"out\": \"%dx%d\", \"pipeline\": \"%s\", \"math\": \"%s\", \"color_stages\": %u, "
-           "\"algorithmic_GBps\": %.1f, \"hbm_peak_frac\": %.4f, \"rccl_ranks\": %d, \"ring\": %d, \"per_gpu_ms\": [",
+           "\"algorithmic_GBps\": %.1f, \"hbm_peak_frac\": %.4f, \"rccl_ranks\": %d, \"ring\": %d, \"bands\": %d, \"per_gpu_ms\": [",
            (double)pixels / sec / 1e6, o.gpus, (unsigned long long)frames, o.steps, sec, o.in_w, o.in_h, o.out_w, o.out_h,
            o.pipeline == 0 ? "two-pass" : (o.pipeline == 1 ? "fused" : (o.pipeline == 2 ? "easu" : "auto")), o.math == FSR1_FLAG_MATH_EXACT ? "exact" : (o.math ? "h" : "f"), o.stages, bytes / sec / 1e9,
-           bytes / sec / 1e9 / (8000.0 * o.gpus), o.gpus, ws[0].ring);
+           bytes / sec / 1e9 / (8000.0 * o.gpus), o.gpus, ws[0].ring, o.bands);
     for (int i = 0; i < o.gpus; ++i) printf("%s%.3f", i ? ", " : "", (double)gathered[3 * i + 2] * 1e-6);
     printf("]}\n");
   }

@@ -1,0 +1,75 @@
+"""Row bands of one frame (a single frame split over several GPUs with zero exchange — every GPU holds the
+input, runs EASU on its band plus one row either side and RCAS on the band).  Here the bands are computed one after the
+other on one GPU and must reassemble into the full-frame result BIT FOR BIT, for both arithmetics: the position arithmetic
+of ffx_fsr1.h:324-326 runs on full-image coordinates whatever the band, and the rows RCAS reads across a band boundary are
+real EASU rows, not the zeros of the image border (FSR_Pass.hlsl:61)."""
+import importlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+frames = importlib.import_module("fidelityfx-fsr_amd.frames")
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def splits(total, n, even):
+    """n bands covering [0, total): boundaries rounded to even rows when `even` (the exact-2x kernel's quads), arbitrary otherwise"""
+    cuts = [0]
+    for k in range(1, n):
+        c = total * k // n + (0 if even else 1)
+        c = c // 2 * 2 if even else c | 1
+        cuts.append(min(max(c, cuts[-1] + 1), total - 1))
+    return list(zip(cuts, cuts[1:] + [total]))
+
+
+@pytest.mark.parametrize("shape", [(960, 540, 1920, 1080), (640, 360, 960, 540), (97, 61, 131, 83), (64, 40, 128, 80)],
+                         ids=lambda s: "%dx%d_to_%dx%d" % s)
+@pytest.mark.parametrize("n_bands", [2, 3, 5])
+def test_bands_reassemble_into_the_full_frame(fsr, shape, n_bands):
+    iw, ih, ow, oh = shape
+    src = dev(frames.synthetic_frame(iw, ih, k=8, dtype=np.float16))
+    for flags in (0, fsr.FLAG_MATH_EXACT):
+        mid = torch.zeros(oh, ow, 4, dtype=torch.float16, device="cuda")
+        full = torch.zeros_like(mid)
+        fsr.easu(src, mid, flags=flags)
+        fsr.rcas(mid, full, sharpness=0.25, flags=flags)
+        for even in (True, False):
+            out = torch.full_like(full, -1.0)
+            for (y0, y1) in splits(oh, n_bands, even):
+                fsr.upscale_band(src, out[y0:y1], (ow, oh), (y0, y1), sharpness=0.25, flags=flags)
+            assert torch.equal(out.view(torch.int16), full.view(torch.int16)), "bands %s (flags %d, even %s) differ from the full frame" % (
+                splits(oh, n_bands, even), flags, even)
+
+
+def test_easu_band_window_with_x_origin(fsr):
+    """A window with an x origin as well (a tile of the output, not just a row band), RGBA32F: equals the same window of the full EASU."""
+    iw, ih, ow, oh = 200, 120, 300, 180
+    src = dev(frames.synthetic_frame(iw, ih, k=3, dtype=np.float32))
+    con = fsr.FsrEasuCon(iw, ih, iw, ih, ow, oh)
+    full = torch.zeros(oh, ow, 4, dtype=torch.float32, device="cuda")
+    fsr.easu(src, full, con=con, flags=fsr.FLAG_MATH_EXACT)
+    for (x0, y0, w, h) in ((0, 0, 300, 180), (64, 16, 100, 50), (37, 91, 263, 89), (299, 179, 1, 1)):
+        win = torch.zeros(h, w, 4, dtype=torch.float32, device="cuda")
+        fsr.easu_band(src, win, con, origin=(x0, y0), flags=fsr.FLAG_MATH_EXACT)
+        assert torch.equal(win, full[y0:y0 + h, x0:x0 + w]), (x0, y0, w, h)
+
+
+def test_band_argument_validation(fsr):
+    src = dev(frames.synthetic_frame(32, 18, k=1, dtype=np.float16))
+    band = torch.zeros(10, 64, 4, dtype=torch.float16, device="cuda")
+    con = fsr.FsrEasuCon(32, 18, 32, 18, 64, 36)
+    with pytest.raises(fsr.Fsr1Error):
+        fsr.easu_band(src, band, con, origin=(0, -2))
+    with pytest.raises(fsr.Fsr1Error):
+        fsr.easu_band(src, band, con, origin=(0, 4), flags=fsr.FLAG_MATH_PACKED_FP16)
+    mid = torch.zeros(12, 64, 4, dtype=torch.float16, device="cuda")
+    with pytest.raises(fsr.Fsr1Error):
+        fsr.rcas_band(mid[1:11], band, rows_above=2, rows_below=0)
+    with pytest.raises(fsr.Fsr1Error):  # the row above the view is the output buffer itself: overlap
+        fsr.rcas_band(mid[1:11], mid[0:10], rows_above=1, rows_below=0)

@@ -74,3 +74,15 @@ def test_runner_two_gpus_over_rccl(runner, fsr):
     d = json.loads(out.stdout.strip().splitlines()[-1])
     assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["frames"] == 100 and len(d["per_gpu_ms"]) == 2
     assert all(ms > 0 for ms in d["per_gpu_ms"])
+
+
+@pytest.mark.gpu
+def test_runner_row_bands(runner):
+    """--bands: one frame stream split into row bands (here a single band on one GPU; per-band parity with the full frame is
+    tests/test_gpu_bands.py's job).  The pixel count is the whole frame's."""
+    out = subprocess.run([runner, "--gpus", "1", "--bands", "--in", "960x540", "--out", "1920x1080", "--steps", "10", "--warmup", "2"],
+                         capture_output=True, text=True, timeout=1200)
+    assert out.returncode == 0, out.stdout + out.stderr
+    d = json.loads(out.stdout.strip().splitlines()[-1])
+    assert d["bands"] == 1 and d["frames"] == 10 and d["value"] > 1000.0
+    assert subprocess.run([runner, "--bands", "--pipeline", "fused"], capture_output=True, text=True, timeout=60).returncode == 2
