@@ -66,6 +66,7 @@ SYMBOLS = {
     "fsr1_easu_rcas_fused_dispatch": (ctypes.c_int, [ctypes.POINTER(fsr1_image)] * 2 + [_U32P, _U32P, ctypes.c_uint32, ctypes.c_void_p]),
     "fsr1_easu_dispatch_band": (ctypes.c_int, [_IMG, _IMG, _U32P, ctypes.c_uint32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p]),
     "fsr1_rcas_dispatch_band": (ctypes.c_int, [_IMG, _IMG, _U32P, ctypes.c_uint32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p]),
+    "fsr1_easu_rcas_fused_dispatch_band": (ctypes.c_int, [_IMG, _IMG, _U32P, _U32P, ctypes.c_uint32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p]),
     "fsr1_color_dispatch": (ctypes.c_int, [_IMG, _IMG, _STG, ctypes.c_uint32, ctypes.c_void_p]),
     "fsr1_easu_dispatch_ex": (ctypes.c_int, [_IMG, _IMG, _U32P, ctypes.c_uint32, _STG, ctypes.c_void_p]),
     "fsr1_rcas_dispatch_ex": (ctypes.c_int, [_IMG, _IMG, _U32P, ctypes.c_uint32, _STG, ctypes.c_void_p]),

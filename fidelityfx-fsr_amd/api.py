@@ -210,15 +210,29 @@ def rcas_band(src_band, dst_band, con=None, sharpness=0.25, rows_above=0, rows_b
     return dst_band
 
 
-def upscale_band(src, dst_band, out_size, band, mid=None, sharpness=0.25, flags=0, stream=None):
+def easu_rcas_fused_band(src, dst_band, easu_con, rcas_con=None, sharpness=0.25, origin_y=0, rows_above=0, rows_below=0, flags=0, stream=None):
+    """dst_band = rows [origin_y, origin_y + rows) of RCAS(EASU(src)) in one launch; rows_above / rows_below = 1 when the full
+    output image `easu_con` describes has a row above / below the band."""
+    i, o = image_of(src), image_of(dst_band)
+    easu_con = _con(easu_con, 16)
+    rcas_con = _con(FsrRcasCon(sharpness) if rcas_con is None else rcas_con, 4)
+    _lib.check(_lib.load().fsr1_easu_rcas_fused_dispatch_band(ctypes.byref(i), ctypes.byref(o), _u32p(easu_con), _u32p(rcas_con), flags,
+                                                              int(origin_y), int(rows_above), int(rows_below), _stream_ptr(stream)))
+    return dst_band
+
+
+def upscale_band(src, dst_band, out_size, band, mid=None, sharpness=0.25, flags=0, stream=None, fused=False):
     """EASU + RCAS for output rows [band[0], band[1]) of an `out_size` = (width, height) upscale of `src`, written to `dst_band`
     (band[1] - band[0] rows): what one GPU does when a single frame is split into row bands.  `mid` (optional)
-    is a scratch tensor of at least band rows + 2; returns dst_band."""
+    is a scratch tensor of at least band rows + 2; fused=True takes the single launch (no intermediary); returns dst_band."""
     import torch
     ow, oh = out_size
     y0, y1 = band
     i = image_of(src)
     con = FsrEasuCon(i.width, i.height, i.width, i.height, ow, oh)
+    if fused:
+        return easu_rcas_fused_band(src, dst_band, con, sharpness=sharpness, origin_y=y0, rows_above=int(y0 > 0), rows_below=int(y1 < oh),
+                                    flags=flags, stream=stream)
     m0, m1 = max(y0 - 1, 0), min(y1 + 1, oh)  # EASU rows the band's RCAS taps read
     if mid is None:
         mid = torch.empty(m1 - m0, ow, 4, dtype=dst_band.dtype, device=dst_band.device)

@@ -135,14 +135,15 @@ static bool overlaps(const fsr1_image* a, const ImageView& va, const fsr1_image*
 // `apron` = 1 for the fused kernel, whose tiles compute one extra pixel on each side (clipped to the image).
 // Exactness matters: LDS per workgroup decides how many workgroups a CU holds (35x11 texels x 48 B lets 8 of them
 // in at 2x; two texels of slack per axis would leave 6).
-static int footprint_extent(int out_size, int tile, int apron, float scale, float bias, int origin = 0) {
+// `lo` / `hi`: rows (columns) the apron may reach beyond the image (a band with neighbouring rows in the full image).
+static int footprint_extent(int out_size, int tile, int apron, float scale, float bias, int origin = 0, int lo = 0, int hi = 0) {
   if (!(scale > 0.0f) || !std::isfinite(scale) || !std::isfinite(bias)) return -1;
   if ((double)(tile + 2 * apron) * (double)scale > 4096.0) return -1;
   const int tiles = (out_size + tile - 1) / tile;
   int best = 0;
   for (int t = 0; t < tiles; ++t) {
-    const int o0 = std::max(t * tile - apron, 0) + origin;  // `origin`: the image is a band of a larger output image
-    const int ol = std::min(t * tile + tile - 1 + apron, out_size - 1) + origin;
+    const int o0 = std::max(t * tile - apron, -lo) + origin;  // `origin`: the image is a band of a larger output image
+    const int ol = std::min(t * tile + tile - 1 + apron, out_size - 1 + hi) + origin;
     const float p0 = (float)o0 * scale, pl = (float)ol * scale;  // two roundings each, as on the device
     const int f0 = (int)std::floor(p0 + bias), fl = (int)std::floor(pl + bias);
     best = std::max(best, fl - f0 + 4);
@@ -382,9 +383,30 @@ int fsr1_easu_rcas_fused_dispatch(const fsr1_image* in, const fsr1_image* out, c
   return fsr1_easu_rcas_fused_dispatch_ex(in, out, easu_con, rcas_con, flags, nullptr, stream);
 }
 
+static int fused_dispatch_impl(const fsr1_image* in, const fsr1_image* out, const uint32_t easu_con[16], const uint32_t rcas_con[4],
+                               uint32_t flags, const fsr1_color_stages* stages, int origin_y, int rows_above, int rows_below, void* stream);
+
 int fsr1_easu_rcas_fused_dispatch_ex(const fsr1_image* in, const fsr1_image* out, const uint32_t easu_con[16],
                                      const uint32_t rcas_con[4], uint32_t flags, const fsr1_color_stages* stages,
                                      void* stream) {
+  return fused_dispatch_impl(in, out, easu_con, rcas_con, flags, stages, 0, 0, 0, stream);
+}
+
+// The single launch on a band of output rows: `out` holds rows [origin_y, origin_y + out->height) of the image
+// `easu_con` was set up for; where that image has a row above / below the band (rows_above / rows_below = 1) the tile aprons
+// compute it with EASU instead of taking it as outside the image, so the band equals the same rows of a full-frame launch.
+int fsr1_easu_rcas_fused_dispatch_band(const fsr1_image* in, const fsr1_image* out, const uint32_t easu_con[16],
+                                       const uint32_t rcas_con[4], uint32_t flags, int32_t origin_y, int32_t rows_above,
+                                       int32_t rows_below, void* stream) {
+  if (origin_y < 0 || origin_y > (1 << 20)) return fail(FSR1_ERR_INVALID_ARGUMENT, "fused band: origin_y %d out of range", origin_y);
+  if ((rows_above | rows_below) & ~1) return fail(FSR1_ERR_INVALID_ARGUMENT, "fused band: rows_above / rows_below must be 0 or 1");
+  if (rows_above && origin_y < 1) return fail(FSR1_ERR_INVALID_ARGUMENT, "fused band: rows_above = 1 needs origin_y >= 1");
+  if (flags & FSR1_FLAG_MATH_PACKED_FP16) return fail(FSR1_ERR_UNSUPPORTED, "fused band: bands run with the F (binary32) arithmetic");
+  return fused_dispatch_impl(in, out, easu_con, rcas_con, flags, nullptr, origin_y, rows_above, rows_below, stream);
+}
+
+static int fused_dispatch_impl(const fsr1_image* in, const fsr1_image* out, const uint32_t easu_con[16], const uint32_t rcas_con[4],
+                               uint32_t flags, const fsr1_color_stages* stages, int origin_y, int rows_above, int rows_below, void* stream) {
   const Range range("easu_rcas_fused", in, out);
   FusedArgs a;
   int rc;
@@ -408,7 +430,10 @@ int fsr1_easu_rcas_fused_dispatch_ex(const fsr1_image* in, const fsr1_image* out
   memcpy(&bx, &easu_con[2], 4);
   memcpy(&by, &easu_con[3], 4);
   a.fp_w = footprint_extent(out->width, kTileW, 1, sx, bx);
-  a.fp_h = footprint_extent(out->height, kFusedTileH, 1, sy, by);
+  a.fp_h = footprint_extent(out->height, kFusedTileH, 1, sy, by, origin_y, rows_above, rows_below);
+  a.origin_y = origin_y;
+  a.rows_above = rows_above;
+  a.rows_below = rows_below;
   if (a.fp_w < 0 || a.fp_h < 0) return fail(FSR1_ERR_INVALID_ARGUMENT, "fused: scale constants con0.xy = (%g, %g) are not usable", sx, sy);
   if ((packed ? fused_h_lds_bytes(a.fp_w, a.fp_h) : fused_lds_bytes(in->format, a.fp_w, a.fp_h)) > 160 * 1024)
     return fail(FSR1_ERR_UNSUPPORTED, "fused: input/output ratio (%g, %g) needs more LDS than a CU has", sx, sy);

@@ -60,6 +60,9 @@ struct FusedArgs {
   int fp_w, fp_h;
   uint32_t flags;
   ColorArgs color;
+  // band of a larger output image (fsr1_easu_rcas_fused_dispatch_band): output row 0 is row origin_y of the image the EASU
+  // constants describe; rows_above / rows_below (0 or 1): that image has a row above / below the band, which the apron computes
+  int origin_y, rows_above, rows_below;
 };
 
 // XCD-aware workgroup -> tile mapping.  Consecutive workgroup ids round-robin over the 8 XCDs

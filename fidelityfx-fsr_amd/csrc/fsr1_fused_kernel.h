@@ -34,13 +34,15 @@ __global__ void __launch_bounds__(kThreads) fused_kernel(const FusedArgs a) {
 
   const float c0x = as_f32(a.easu_con[0]), c0y = as_f32(a.easu_con[1]), c0z = as_f32(a.easu_con[2]), c0w = as_f32(a.easu_con[3]);
 
-  // apron tile = output pixels [ox0-1, ox0+64] x [oy0-1, oy0+16], clipped to the image for the footprint
-  const int ax0 = max(ox0 - 1, 0), ay0 = max(oy0 - 1, 0);
-  const int axl = min(ox0 + kTileW, W - 1), ayl = min(oy0 + kFusedTileH, H - 1);
+  // apron tile = output pixels [ox0-1, ox0+64] x [oy0-1, oy0+16], clipped to the image for the footprint (a band's image
+  // reaches one row beyond the band where rows_above / rows_below say so; rows are positioned in the full image)
+  const int ylo = -a.rows_above, yhi = H - 1 + a.rows_below, yorg = a.origin_y;
+  const int ax0 = max(ox0 - 1, 0), ay0 = max(oy0 - 1, ylo);
+  const int axl = min(ox0 + kTileW, W - 1), ayl = min(oy0 + kFusedTileH, yhi);
   const int fx0 = (int)floorf((float)ax0 * c0x + c0z) - 1;
-  const int fy0 = (int)floorf((float)ay0 * c0y + c0w) - 1;
+  const int fy0 = (int)floorf((float)(ay0 + yorg) * c0y + c0w) - 1;
   const int fw = min((int)floorf((float)axl * c0x + c0z) + 2 - fx0 + 1, a.fp_w);
-  const int fh = min((int)floorf((float)ayl * c0y + c0w) + 2 - fy0 + 1, a.fp_h);
+  const int fh = min((int)floorf((float)(ayl + yorg) * c0y + c0w) + 2 - fy0 + 1, a.fp_h);
   l.fw = fw;
 
   const int tid = threadIdx.x;
@@ -53,8 +55,8 @@ __global__ void __launch_bounds__(kThreads) fused_kernel(const FusedArgs a) {
   auto easu_to_mid = [&](int mx, int my, float ppx, int lxf, bool x_ok) {
     const int oy = oy0 - 1 + my;
     texel_t px = Pixel<FMT>::zero();
-    if (x_ok && oy >= 0 && oy < H) {
-      float ppy = (float)oy * c0y + c0w;  // :324-326
+    if (x_ok && oy >= ylo && oy <= yhi) {
+      float ppy = (float)(oy + yorg) * c0y + c0w;  // :324-326
       const float fpy = floorf(ppy);
       ppy -= fpy;
       const int f_idx = ((int)fpy - fy0) * fw + lxf;

@@ -210,12 +210,19 @@ int fsr1_easu_rcas_fused_dispatch_ex(const fsr1_image* in, const fsr1_image* out
  *   2. fsr1_rcas_dispatch_band sharpens the band's own rows: `in` describes them, rows_above / rows_below (0 or 1)
  *      say that the row just above / below exists in memory (the extra EASU rows of step 1) and is to be read
  *      instead of being treated as outside the image (= 0).
+ * fsr1_easu_rcas_fused_dispatch_band is the single-launch form of the two steps: `out` holds output rows
+ * [origin_y, origin_y + out->height) of the full image, and where rows_above / rows_below say that the full image
+ * has a row above / below the band, the tile aprons compute that row with EASU (full-image coordinates) instead of
+ * treating it as outside the image.  No intermediary; bit-identical to the same rows of a full-frame launch.
  * F arithmetic (default or FSR1_FLAG_MATH_EXACT), one frame per dispatch for the RCAS band.
  * ---------------------------------------------------------------------------------------------- */
 int fsr1_easu_dispatch_band(const fsr1_image* in, const fsr1_image* out, const uint32_t con[16], uint32_t flags,
                             int32_t origin_x, int32_t origin_y, void* stream);
 int fsr1_rcas_dispatch_band(const fsr1_image* in, const fsr1_image* out, const uint32_t con[4], uint32_t flags,
                             int32_t rows_above, int32_t rows_below, void* stream);
+int fsr1_easu_rcas_fused_dispatch_band(const fsr1_image* in, const fsr1_image* out, const uint32_t easu_con[16],
+                                       const uint32_t rcas_con[4], uint32_t flags, int32_t origin_y, int32_t rows_above,
+                                       int32_t rows_below, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * FSR_Filter::Upscale (sample/src/DX12/FSR_Filter.cpp:101-141) as one call.

@@ -18,7 +18,8 @@
  *
  * --bands: strong scaling of ONE frame stream instead of weak scaling over frames — every GPU holds the whole
  * input frame and produces one band of output rows (fsr1_easu_dispatch_band on the band plus a row either side, then
- * fsr1_rcas_dispatch_band); still no image byte crosses a link.
+ * fsr1_rcas_dispatch_band, or with --pipeline fused the single launch fsr1_easu_rcas_fused_dispatch_band); still no image
+ * byte crosses a link.
  *
  * --stages fuses colour stages into the passes (FSR1_COLOR_* bits of fsr1_hip.h: 1 FsrSrtmF on the input, 2 FsrLfgaF
  * film grain, 4 FsrSrtmInvF, 8 / 16 FsrTepdC8F / FsrTepdC10F dither) — what the sample's colour pass does around the
@@ -160,7 +161,7 @@ static int worker_body_bands(worker_t* w) {
   w->ring = ring;
   if (rows > 0) {
     HIP_OK(w, hipMalloc(&w->d_in, in_frame * ring));
-    HIP_OK(w, hipMalloc(&w->d_mid, pitch * (size_t)(m1 - m0)));
+    if (o->pipeline != 1) HIP_OK(w, hipMalloc(&w->d_mid, pitch * (size_t)(m1 - m0)));
     HIP_OK(w, hipMalloc(&w->d_out, pitch * (size_t)rows * ring));
     uint16_t* host = (uint16_t*)malloc(in_frame);
     if (!host) { snprintf(w->error, sizeof w->error, "out of host memory"); w->status = -1; return -1; }
@@ -185,8 +186,12 @@ static int worker_body_bands(worker_t* w) {
       fsr1_image mid = {w->d_mid, o->out_w, m1 - m0, FSR1_FORMAT_RGBA16F, 1, 0, 0};
       fsr1_image mid_band = {(char*)w->d_mid + pitch * (size_t)(y0 - m0), o->out_w, rows, FSR1_FORMAT_RGBA16F, 1, 0, 0};
       fsr1_image out = {(char*)w->d_out + pitch * (size_t)rows * s, o->out_w, rows, FSR1_FORMAT_RGBA16F, 1, 0, 0};
-      FSR_OK(w, fsr1_easu_dispatch_band(&in, &mid, easu, o->math, 0, m0, stream));
-      FSR_OK(w, fsr1_rcas_dispatch_band(&mid_band, &out, rcas, o->math | (o->hdr ? FSR1_FLAG_HDR_SQUARE : 0u), m0 < y0, m1 > y1, stream));
+      if (o->pipeline == 1) { /* single launch: the aprons compute the rows beyond the band */
+        FSR_OK(w, fsr1_easu_rcas_fused_dispatch_band(&in, &out, easu, rcas, o->math | (o->hdr ? FSR1_FLAG_HDR_SQUARE : 0u), y0, m0 < y0, m1 > y1, stream));
+      } else {
+        FSR_OK(w, fsr1_easu_dispatch_band(&in, &mid, easu, o->math, 0, m0, stream));
+        FSR_OK(w, fsr1_rcas_dispatch_band(&mid_band, &out, rcas, o->math | (o->hdr ? FSR1_FLAG_HDR_SQUARE : 0u), m0 < y0, m1 > y1, stream));
+      }
     }
     HIP_OK(w, hipEventRecord(w->ev1, stream));
     HIP_OK(w, hipEventSynchronize(w->ev1));
@@ -359,8 +364,8 @@ int main(int argc, char** argv) {
   const int visible = fsr1_device_count();
   if (visible < 0) { fprintf(stderr, "cannot enumerate GPUs: %s\n", fsr1_last_error()); return 1; }
   if (visible < o.gpus) { fprintf(stderr, "need %d GPUs, %d visible\n", o.gpus, visible); return 1; }
-  if (o.bands && (o.pipeline != 0 || o.stages || (o.math & FSR1_FLAG_MATH_PACKED_FP16))) {
-    fprintf(stderr, "--bands runs the two F dispatches without colour stages\n");
+  if (o.bands && (o.pipeline > 1 || o.stages || (o.math & FSR1_FLAG_MATH_PACKED_FP16))) {
+    fprintf(stderr, "--bands runs the two F dispatches or the fused launch, without colour stages\n");
     return 2;
   }
   if ((o.math & FSR1_FLAG_MATH_PACKED_FP16) && o.stages) {

@@ -47,6 +47,49 @@ def test_bands_reassemble_into_the_full_frame(fsr, shape, n_bands):
                 splits(oh, n_bands, even), flags, even)
 
 
+@pytest.mark.parametrize("shape", [(960, 540, 1920, 1080), (640, 360, 960, 540), (97, 61, 131, 83), (64, 40, 128, 80), (150, 90, 195, 117)],
+                         ids=lambda s: "%dx%d_to_%dx%d" % s)
+@pytest.mark.parametrize("n_bands", [2, 3, 7])
+def test_fused_bands_reassemble_into_the_full_frame(fsr, shape, n_bands):
+    """The single-launch band form: the tile aprons compute the rows beyond a band boundary with EASU on full-image
+    coordinates, so the bands equal the full-frame fused launch — and hence the two dispatches — bit for bit."""
+    iw, ih, ow, oh = shape
+    src = dev(frames.synthetic_frame(iw, ih, k=11, dtype=np.float16))
+    for flags in (0, fsr.FLAG_MATH_EXACT, fsr.FLAG_RCAS_DENOISE):
+        full = torch.zeros(oh, ow, 4, dtype=torch.float16, device="cuda")
+        fsr.easu_rcas_fused(src, full, sharpness=0.25, flags=flags)
+        for even in (True, False):
+            out = torch.full_like(full, -1.0)
+            for (y0, y1) in splits(oh, n_bands, even):
+                fsr.upscale_band(src, out[y0:y1], (ow, oh), (y0, y1), sharpness=0.25, flags=flags, fused=True)
+            assert torch.equal(out.view(torch.int16), full.view(torch.int16)), "fused bands %s (flags %d, even %s) differ from the full frame" % (
+                splits(oh, n_bands, even), flags, even)
+    two = torch.zeros_like(full)
+    for (y0, y1) in splits(oh, n_bands, False):
+        fsr.upscale_band(src, two[y0:y1], (ow, oh), (y0, y1), sharpness=0.25, flags=fsr.FLAG_RCAS_DENOISE)
+    assert torch.equal(two.view(torch.int16), full.view(torch.int16))  # two-dispatch bands == fused full frame
+
+
+def test_fused_band_batch_and_rgba8(fsr):
+    """Several frames per launch share the band geometry; UNORM storage goes through the same apron logic."""
+    iw, ih, ow, oh = 96, 54, 192, 108
+    src = torch.stack([dev(frames.synthetic_frame(iw, ih, k=k, dtype=np.float16)) for k in range(3)])
+    full = torch.zeros(3, oh, ow, 4, dtype=torch.float16, device="cuda")
+    fsr.easu_rcas_fused(src, full, sharpness=0.4)
+    con = fsr.FsrEasuCon(iw, ih, iw, ih, ow, oh)
+    out = torch.full_like(full, -1.0)
+    for (y0, y1) in ((0, 37), (37, 90), (90, 108)):
+        fsr.easu_rcas_fused_band(src, out[:, y0:y1], con, sharpness=0.4, origin_y=y0, rows_above=int(y0 > 0), rows_below=int(y1 < oh))
+    assert torch.equal(out.view(torch.int16), full.view(torch.int16))
+    src8 = (src[0].float().clamp(0, 1) * 255 + 0.5).floor().to(torch.uint8)
+    full8 = torch.zeros(oh, ow, 4, dtype=torch.uint8, device="cuda")
+    fsr.easu_rcas_fused(src8, full8, sharpness=0.4, flags=fsr.FLAG_MATH_EXACT)
+    out8 = torch.zeros_like(full8)
+    for (y0, y1) in ((0, 50), (50, 51), (51, 108)):
+        fsr.easu_rcas_fused_band(src8, out8[y0:y1], con, sharpness=0.4, origin_y=y0, rows_above=int(y0 > 0), rows_below=int(y1 < oh), flags=fsr.FLAG_MATH_EXACT)
+    assert torch.equal(out8, full8)
+
+
 def test_easu_band_window_with_x_origin(fsr):
     """A window with an x origin as well (a tile of the output, not just a row band), RGBA32F: equals the same window of the full EASU."""
     iw, ih, ow, oh = 200, 120, 300, 180
@@ -73,3 +116,9 @@ def test_band_argument_validation(fsr):
         fsr.rcas_band(mid[1:11], band, rows_above=2, rows_below=0)
     with pytest.raises(fsr.Fsr1Error):  # the row above the view is the output buffer itself: overlap
         fsr.rcas_band(mid[1:11], mid[0:10], rows_above=1, rows_below=0)
+    with pytest.raises(fsr.Fsr1Error):
+        fsr.easu_rcas_fused_band(src, band, con, origin_y=0, rows_above=1)  # no row above row 0
+    with pytest.raises(fsr.Fsr1Error):
+        fsr.easu_rcas_fused_band(src, band, con, origin_y=4, rows_above=1, rows_below=3)
+    with pytest.raises(fsr.Fsr1Error):
+        fsr.easu_rcas_fused_band(src, band, con, origin_y=4, rows_above=1, rows_below=1, flags=fsr.FLAG_MATH_PACKED_FP16)

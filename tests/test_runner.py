@@ -85,4 +85,9 @@ def test_runner_row_bands(runner):
     assert out.returncode == 0, out.stdout + out.stderr
     d = json.loads(out.stdout.strip().splitlines()[-1])
     assert d["bands"] == 1 and d["frames"] == 10 and d["value"] > 1000.0
-    assert subprocess.run([runner, "--bands", "--pipeline", "fused"], capture_output=True, text=True, timeout=60).returncode == 2
+    fused = subprocess.run([runner, "--gpus", "1", "--bands", "--pipeline", "fused", "--in", "960x540", "--out", "1920x1080", "--steps", "10", "--warmup", "2"],
+                           capture_output=True, text=True, timeout=1200)
+    assert fused.returncode == 0, fused.stdout + fused.stderr
+    d = json.loads(fused.stdout.strip().splitlines()[-1])
+    assert d["bands"] == 1 and d["pipeline"] == "fused" and d["value"] > 1000.0
+    assert subprocess.run([runner, "--bands", "--pipeline", "easu"], capture_output=True, text=True, timeout=60).returncode == 2
