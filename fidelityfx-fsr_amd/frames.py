@@ -75,3 +75,24 @@ def kat_frame_64x36():
     img[..., 2] = np.float32(0.25) + np.float32(0.5) * e * rnd[..., 1]
     img[..., 3] = 1.0
     return img
+
+
+def adversarial_frame(width, height, k=0, dtype=np.float16):
+    """A frame of finite but hostile binary16 values for the special-value parity tests: HDR highlights up to the top of
+    the binary16 range, exact zeros, negative (scRGB) texels, binary16 subnormals and isolated single-texel spikes on top of
+    `synthetic_frame`.  No Inf / NaN inputs: what the shading languages' min / max do with those is not defined by the
+    reference; Inf and NaN that the arithmetic itself produces from these inputs are part of the comparison."""
+    img = synthetic_frame(width, height, k=k, dtype=np.float32)
+    y, x = np.meshgrid(np.arange(height, dtype=np.int64), np.arange(width, dtype=np.int64), indexing="ij")
+    seed = (0x85EBCA6B * (k + 3)) & 0xFFFFFFFF
+    u = _hash_noise(x, y, seed)                  # [0, 1)
+    sel = _hash_noise(x // 3, y // 2, seed ^ 0x5bd1e995)  # small patches share a class
+    gain = np.select([sel < 0.55, sel < 0.70, sel < 0.80], [1.0, 8.0, 512.0], 60000.0).astype(np.float32)
+    img[..., :3] = np.minimum(img[..., :3] * gain[..., None], np.float32(65504.0))
+    img[(u < 0.04), :3] = 0.0
+    img[(u >= 0.04) & (u < 0.07), :3] *= -1.0
+    img[(u >= 0.07) & (u < 0.10), :3] = np.float32(3.0e-6)      # binary16 subnormal
+    img[(u >= 0.10) & (u < 0.12), :3] = np.float32(5.9604645e-8)  # the smallest one
+    img[(u >= 0.12) & (u < 0.13), 0] = np.float32(65504.0)       # single-channel spikes
+    img[(u >= 0.13) & (u < 0.14), 2] = np.float32(6.1035156e-5)  # smallest normal
+    return img.astype(np.float16).astype(dtype)

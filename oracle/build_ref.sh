@@ -6,7 +6,7 @@
 #     `out`/`inout` parameter qualifiers have no C++ spelling, so a sed pass writes a *temporary*
 #     copy of the two headers with `out T x`/`inout T x` -> `T& x` (and the in*/out*/inout* macro
 #     family of ffx_a.h:2435-2472 mapped likewise); the temp dir is deleted after compiling.
-# Pinned semantics: -ffp-contract=off, IEEE minNum/maxNum, correctly rounded 1/x (see shim header).
+# Pinned semantics: -ffp-contract=off, IEEE minNum/maxNum with -0 < +0, correctly rounded 1/x (see shim header).
 # When /root/reference is absent (the GPU box) the prebuilt .so that travelled with the tree is kept.
 set -euo pipefail
 HERE=$(cd "$(dirname "$0")" && pwd)

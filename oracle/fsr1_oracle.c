@@ -11,7 +11,8 @@
  *
  * Pinned semantics (the shading languages leave these open; same choices as oracle/_ref):
  *   - no FMA contraction: build with -ffp-contract=off; expressions keep the reference's order
- *   - min/max are IEEE minNum/maxNum (fminf/fmaxf)
+ *   - min/max are IEEE minNum/maxNum (a NaN operand loses) with -0 < +0, as v_min_f32 / v_max_f32 and their _f16 forms
+ *     evaluate them on the GPUs the reference's shaders run on; C's fminf / fmaxf may return either zero
  *   - ARcpF1 is the correctly rounded 1.0f/x
  *   - EASU taps are clamped to the resource edge; RCAS loads outside the image return 0
  *   - "H" (16-bit) arithmetic: each operation rounded once to binary16, round-to-nearest-even,
@@ -33,6 +34,8 @@ enum { ORACLE_RCAS_DENOISE = 1, ORACLE_RCAS_ALPHA = 2, ORACLE_HDR_SQUARE = 4 };
 
 static inline uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
 static inline float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+static inline float omin(float a, float b) { return (a == 0.0f && b == 0.0f) ? (signbit(a) ? a : b) : fminf(a, b); }  /* -0 < +0 */
+static inline float omax(float a, float b) { return (a == 0.0f && b == 0.0f) ? (signbit(a) ? b : a) : fmaxf(a, b); }
 
 /* ------------------------------------------------------------------------------------------ */
 /* constant setup                                                                             */
@@ -95,9 +98,9 @@ void oracle_FsrRcasCon(uint32_t* con, float sharpness) {
 static inline float APrxLoRcpF1(float a) { return u2f(0x7ef07ebbu - f2u(a)); }                 /* :1843 */
 static inline float APrxMedRcpF1(float a) { float b = u2f(0x7ef19fffu - f2u(a)); return b * (-b * a + 2.0f); } /* :1844 */
 static inline float APrxLoRsqF1(float a) { return u2f(0x5f347d74u - (f2u(a) >> 1)); }          /* :1845 */
-static inline float ASatF1(float x) { return fminf(fmaxf(x, 0.0f), 1.0f); }                    /* :747 clamp(x,0,1) */
-static inline float AMin3F1(float x, float y, float z) { return fminf(x, fminf(y, z)); }        /* :703 */
-static inline float AMax3F1(float x, float y, float z) { return fmaxf(x, fmaxf(y, z)); }        /* :675 */
+static inline float ASatF1(float x) { return omin(omax(x, 0.0f), 1.0f); }                    /* :747 clamp(x,0,1) */
+static inline float AMin3F1(float x, float y, float z) { return omin(x, omin(y, z)); }        /* :703 */
+static inline float AMax3F1(float x, float y, float z) { return omax(x, omax(y, z)); }        /* :675 */
 static inline float ARcpF1(float x) { return 1.0f / x; }                                        /* :737 */
 
 typedef struct { const float* p; int w, h; } image_t;
@@ -116,7 +119,7 @@ static inline const float* texel(const image_t* s, int x, int y) {
 static inline void FsrEasuSetF(float dir[2], float* len, float w, float lA, float lB, float lC, float lD, float lE) {
   float dc = lD - lC;
   float cb = lC - lB;
-  float lenX = fmaxf(fabsf(dc), fabsf(cb));
+  float lenX = omax(fabsf(dc), fabsf(cb));
   lenX = APrxLoRcpF1(lenX);
   float dirX = lD - lB;
   dir[0] += dirX * w;
@@ -125,7 +128,7 @@ static inline void FsrEasuSetF(float dir[2], float* len, float w, float lA, floa
   *len += lenX * w;
   float ec = lE - lC;
   float ca = lC - lA;
-  float lenY = fmaxf(fabsf(ec), fabsf(ca));
+  float lenY = omax(fabsf(ec), fabsf(ca));
   lenY = APrxLoRcpF1(lenY);
   float dirY = lE - lA;
   dir[1] += dirY * w;
@@ -142,7 +145,7 @@ static inline void FsrEasuTapF(float aC[3], float* aW, float offX, float offY, c
   vx *= len[0];
   vy *= len[1];
   float d2 = vx * vx + vy * vy;
-  d2 = fminf(d2, clp);
+  d2 = omin(d2, clp);
   float wB = (float)(2.0 / 5.0) * d2 + -1.0f;
   float wA = lob * d2 + -1.0f;
   wB *= wB;
@@ -195,15 +198,15 @@ static void FsrEasuF(float pix[3], uint32_t ipx, uint32_t ipy, const uint32_t* c
   /* :397-409 */
   len = len * 0.5f;
   len *= len;
-  float stretch = (dir[0] * dir[0] + dir[1] * dir[1]) * APrxLoRcpF1(fmaxf(fabsf(dir[0]), fabsf(dir[1])));
+  float stretch = (dir[0] * dir[0] + dir[1] * dir[1]) * APrxLoRcpF1(omax(fabsf(dir[0]), fabsf(dir[1])));
   float len2[2] = {1.0f + (stretch - 1.0f) * len, 1.0f + -0.5f * len};
   float lob = 0.5f + (float)((1.0 / 4.0 - 0.04) - 0.5) * len;
   float clp = APrxLoRcpF1(lob);
   /* :416-419 min/max of the 4 nearest (f,g,j,k) */
   float min4[3], max4[3];
   for (int ch = 0; ch < 3; ++ch) {
-    min4[ch] = fminf(AMin3F1(f[ch], g[ch], j[ch]), k[ch]);
-    max4[ch] = fmaxf(AMax3F1(f[ch], g[ch], j[ch]), k[ch]);
+    min4[ch] = omin(AMin3F1(f[ch], g[ch], j[ch]), k[ch]);
+    max4[ch] = omax(AMax3F1(f[ch], g[ch], j[ch]), k[ch]);
   }
   /* :421-434 accumulation, reference order b c i j f e k l h g o n */
   float aC[3] = {0.0f, 0.0f, 0.0f};
@@ -222,7 +225,7 @@ static void FsrEasuF(float pix[3], uint32_t ipx, uint32_t ipy, const uint32_t* c
   FsrEasuTapF(aC, &aW, 0.0f - ppx, 2.0f - ppy, dir, len2, lob, clp, n);
   /* :437 normalize and dering */
   float rW = ARcpF1(aW);
-  for (int ch = 0; ch < 3; ++ch) pix[ch] = fminf(max4[ch], fmaxf(min4[ch], aC[ch] * rW));
+  for (int ch = 0; ch < 3; ++ch) pix[ch] = omin(max4[ch], omax(min4[ch], aC[ch] * rW));
 }
 
 /* Rows [y0,y1) of EASU; alpha is written as 1 and `c*=c` applied when flags has HDR_SQUARE
@@ -272,25 +275,25 @@ static void FsrRcasF(float pix[4], int x, int y, const uint32_t* con, const imag
   nz = ASatF1(fabsf(nz) * APrxMedRcpF1(AMax3F1(AMax3F1(bL, dL, eL), fL, hL) - AMin3F1(AMin3F1(bL, dL, eL), fL, hL)));
   nz = -0.5f * nz + 1.0f;
   /* :741-746 */
-  float mn4R = fminf(AMin3F1(bR, dR, fR), hR);
-  float mn4G = fminf(AMin3F1(bG, dG, fG), hG);
-  float mn4B = fminf(AMin3F1(bB, dB, fB), hB);
-  float mx4R = fmaxf(AMax3F1(bR, dR, fR), hR);
-  float mx4G = fmaxf(AMax3F1(bG, dG, fG), hG);
-  float mx4B = fmaxf(AMax3F1(bB, dB, fB), hB);
+  float mn4R = omin(AMin3F1(bR, dR, fR), hR);
+  float mn4G = omin(AMin3F1(bG, dG, fG), hG);
+  float mn4B = omin(AMin3F1(bB, dB, fB), hB);
+  float mx4R = omax(AMax3F1(bR, dR, fR), hR);
+  float mx4G = omax(AMax3F1(bG, dG, fG), hG);
+  float mx4B = omax(AMax3F1(bB, dB, fB), hB);
   /* :748-758 */
   const float peakCx = 1.0f, peakCy = -1.0f * 4.0f;
-  float hitMinR = fminf(mn4R, eR) * ARcpF1(4.0f * mx4R);
-  float hitMinG = fminf(mn4G, eG) * ARcpF1(4.0f * mx4G);
-  float hitMinB = fminf(mn4B, eB) * ARcpF1(4.0f * mx4B);
-  float hitMaxR = (peakCx - fmaxf(mx4R, eR)) * ARcpF1(4.0f * mn4R + peakCy);
-  float hitMaxG = (peakCx - fmaxf(mx4G, eG)) * ARcpF1(4.0f * mn4G + peakCy);
-  float hitMaxB = (peakCx - fmaxf(mx4B, eB)) * ARcpF1(4.0f * mn4B + peakCy);
-  float lobeR = fmaxf(-hitMinR, hitMaxR);
-  float lobeG = fmaxf(-hitMinG, hitMaxG);
-  float lobeB = fmaxf(-hitMinB, hitMaxB);
+  float hitMinR = omin(mn4R, eR) * ARcpF1(4.0f * mx4R);
+  float hitMinG = omin(mn4G, eG) * ARcpF1(4.0f * mx4G);
+  float hitMinB = omin(mn4B, eB) * ARcpF1(4.0f * mx4B);
+  float hitMaxR = (peakCx - omax(mx4R, eR)) * ARcpF1(4.0f * mn4R + peakCy);
+  float hitMaxG = (peakCx - omax(mx4G, eG)) * ARcpF1(4.0f * mn4G + peakCy);
+  float hitMaxB = (peakCx - omax(mx4B, eB)) * ARcpF1(4.0f * mn4B + peakCy);
+  float lobeR = omax(-hitMinR, hitMaxR);
+  float lobeG = omax(-hitMinG, hitMaxG);
+  float lobeB = omax(-hitMinB, hitMaxB);
   /* :759 FSR_RCAS_LIMIT = 0.25-1/16 (:654) */
-  float lobe = fmaxf((float)(-(0.25 - (1.0 / 16.0))), fminf(AMax3F1(lobeR, lobeG, lobeB), 0.0f)) * u2f(con[0]);
+  float lobe = omax((float)(-(0.25 - (1.0 / 16.0))), omin(AMax3F1(lobeR, lobeG, lobeB), 0.0f)) * u2f(con[0]);
   if (flags & ORACLE_RCAS_DENOISE) lobe *= nz;
   /* :765-768 */
   float rcpL = APrxMedRcpF1(4.0f * lobe + 1.0f);
@@ -353,8 +356,8 @@ static inline hf hadd(hf a, hf b) { return hround((double)a + (double)b); }
 static inline hf hsub(hf a, hf b) { return hround((double)a - (double)b); }
 static inline hf hmul(hf a, hf b) { return hround((double)a * (double)b); }
 static inline hf hdiv(hf a, hf b) { return hround((double)a / (double)b); }
-static inline hf hmin(hf a, hf b) { return fminf(a, b); }
-static inline hf hmax(hf a, hf b) { return fmaxf(a, b); }
+static inline hf hmin(hf a, hf b) { return omin(a, b); }
+static inline hf hmax(hf a, hf b) { return omax(a, b); }
 static inline hf hsat(hf a) { return hmin(hmax(a, 0.0f), 1.0f); }                     /* ffx_a.h:896 */
 static inline hf APrxLoRcpH1(hf a) { return hfrombits((uint16_t)(0x7784u - hbits(a))); } /* ffx_a.h:1808 */
 static inline hf APrxMedRcpH1(hf a) {                                                   /* ffx_a.h:1814 */
@@ -607,12 +610,12 @@ static inline void FsrSrtmF(float c[3]) {
 }
 /* :1044 FsrSrtmInvF   c *= rcp(max(1/32768, 1 - max3(c))) */
 static inline void FsrSrtmInvF(float c[3]) {
-  float r = ARcpF1(fmaxf((float)(1.0 / 32768.0), 1.0f - AMax3F1(c[0], c[1], c[2])));
+  float r = ARcpF1(omax((float)(1.0 / 32768.0), 1.0f - AMax3F1(c[0], c[1], c[2])));
   c[0] *= r; c[1] *= r; c[2] *= r;
 }
 /* :1012 FsrLfgaF   c += (t*a) * min(1-c, c) */
 static inline void FsrLfgaF(float c[3], const float t[3], float a) {
-  for (int i = 0; i < 3; ++i) c[i] += (t[i] * a) * fminf(1.0f - c[i], c[i]);
+  for (int i = 0; i < 3; ++i) c[i] += (t[i] * a) * omin(1.0f - c[i], c[i]);
 }
 /* :1082-1091 FsrTepdDitF.  Constant expressions are folded in double and rounded once to float (the pin used
  * for every literal expression of the header). */

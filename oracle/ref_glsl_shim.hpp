@@ -8,7 +8,9 @@
 //
 // Pinned semantics where GLSL/HLSL leave latitude:
 //   * no FMA contraction (build flag -ffp-contract=off)
-//   * min/max = IEEE-754 minNum/maxNum (fminf/fmaxf): a NaN operand loses
+//   * min/max = IEEE-754 minNum/maxNum (a NaN operand loses) with -0 < +0: what v_min_f32 / v_max_f32 and their
+//     _f16 forms do on the GPUs the reference's shaders run on (AMD GCN3 ISA "V_MIN_F32"; PTX min.f32 likewise), where
+//     C's fmin / fmax may return either zero
 //   * 1.0/x is the correctly rounded IEEE division
 //   * float16_t: every operation is computed exactly-enough in double and rounded once to
 //     binary16 round-to-nearest-even (denormals kept, overflow -> inf)
@@ -194,10 +196,12 @@ static inline float abs(float a) { return std::fabs(a); }
 static inline int abs(int a) { return a < 0 ? -a : a; }
 static inline int16_t abs(int16_t a) { return (int16_t)(a < 0 ? -a : a); }
 static inline float16_t abs(float16_t a) { float16_t r; r.v = std::fabs(a.v); return r; }
-static inline float min(float a, float b) { return std::fmin(a, b); }
-static inline float max(float a, float b) { return std::fmax(a, b); }
-static inline float16_t min(float16_t a, float16_t b) { float16_t r; r.v = std::fmin(a.v, b.v); return r; }
-static inline float16_t max(float16_t a, float16_t b) { float16_t r; r.v = std::fmax(a.v, b.v); return r; }
+template <class T> static inline T min_num(T a, T b) { return (a == 0 && b == 0) ? (std::signbit(a) ? a : b) : std::fmin(a, b); }  // -0 < +0
+template <class T> static inline T max_num(T a, T b) { return (a == 0 && b == 0) ? (std::signbit(a) ? b : a) : std::fmax(a, b); }
+static inline float min(float a, float b) { return min_num(a, b); }
+static inline float max(float a, float b) { return max_num(a, b); }
+static inline float16_t min(float16_t a, float16_t b) { float16_t r; r.v = min_num(a.v, b.v); return r; }
+static inline float16_t max(float16_t a, float16_t b) { float16_t r; r.v = max_num(a.v, b.v); return r; }
 static inline uint min(uint a, uint b) { return a < b ? a : b; }
 static inline uint max(uint a, uint b) { return a > b ? a : b; }
 static inline int min(int a, int b) { return a < b ? a : b; }
