@@ -145,3 +145,25 @@ def test_default_arithmetic_on_adversarial_values(fsr, port, shape, record_prope
     record_property("rcas_bit_equal_fraction", fr)
     print("adversarial %s: bit-equal fraction easu %.4f rcas %.4f" % (shape, fe, fr))
     assert fe >= 0.995 and fr >= 0.995
+
+
+@pytest.mark.parametrize("stages", [1, 4, 1 | 4, 2, 1 | 2 | 4, 8, 16, 2 | 8])
+def test_colour_stages_on_adversarial_values(fsr, port, stages):
+    """The colour stages (ffx_fsr1.h:986-1199) on hostile values: EXACT bit-identical in RGBA32F and RGBA16F, the packed-fp16
+    entry points bit-identical to the H oracle (negative and > 1 inputs drive FsrSrtmInvF through its 1/32768 floor, the tone
+    mapper through negative peaks)."""
+    rng = np.random.default_rng(77)
+    noise = (rng.random((2, 8, 12, 4)).astype(np.float32) - np.array([0.5, 0.5, 0.5, 0.0], np.float32)).astype(np.float16)
+    p = dict(amount=0.6, bias=0.05, frame=5, noise_offset=(-3, 17))
+    st = fsr.ColorStages(stages, grain_amount=p["amount"], grain_bias=p["bias"], frame=p["frame"], noise=dev(noise), noise_offset=p["noise_offset"])
+    img = frames.adversarial_frame(70, 41, k=0, dtype=np.float32)
+    want = port.color_f(img, stages, noise=noise.astype(np.float32), **p)
+    for dt in (torch.float32, torch.float16):
+        src = dev(img).to(dt)
+        dst = torch.zeros_like(src)
+        fsr.color(src, dst, st, flags=fsr.FLAG_MATH_EXACT)
+        assert_same(host(dst), want, "colour stages %d EXACT %s" % (stages, dt))
+    src = dev(img).to(torch.float16)
+    dst = torch.zeros_like(src)
+    fsr.color(src, dst, st, flags=fsr.FLAG_MATH_PACKED_FP16)
+    assert_same(host(dst), port.color_h(img, stages, noise=noise.astype(np.float32), **p), "colour stages %d H" % stages)

@@ -36,3 +36,15 @@ def test_port_matches_reference_build_on_adversarial_values(port, ref, shape):
             for fl in (0, 1, 2, 3, 4):
                 assert same_bits(port.rcas_f(mid, rc, fl), ref.rcas_f(mid, rc, fl)), ("rcas_f", k, stops, fl)
                 assert same_bits(port.rcas_h(mid, rc, fl), ref.rcas_h(mid, rc, fl)), ("rcas_h", k, stops, fl)
+
+
+@pytest.mark.parametrize("stages", [1, 4, 1 | 4, 2, 1 | 2 | 4, 8, 16, 2 | 8])
+def test_colour_stages_on_adversarial_values(port, ref, stages):
+    """FsrSrtmF / FsrLfgaF / FsrSrtmInvF / FsrTepdC*F (ffx_fsr1.h:986-1199) on the same hostile values, F and H entry points."""
+    rng = np.random.default_rng(77)
+    noise = (rng.random((2, 8, 12, 4)).astype(np.float32) - np.array([0.5, 0.5, 0.5, 0.0], np.float32)).astype(np.float16).astype(np.float32)
+    for k in (0, 1):
+        img = frames.adversarial_frame(70, 41, k=k, dtype=np.float32)
+        kw = dict(amount=0.6, bias=0.05, frame=5 + k, noise=noise, noise_offset=(-3, 17))
+        assert same_bits(port.color_f(img, stages, **kw), ref.color_f(img, stages, **kw)), ("color_f", k)
+        assert same_bits(port.color_h(img, stages, **kw), ref.color_h(img, stages, **kw)), ("color_h", k)
