@@ -7,8 +7,10 @@
 A "step" is one pass of the hot path over one batch of synthetic frames that are already resident
 in HBM.  Default workload = BASELINE.json configs[1]: 1920x1080 -> 3840x2160, EASU + RCAS, RGBA16F
 storage, one frame per step and per GPU, default ("F") arithmetic = fp32 math within 1 binary16 ULP of
-the reference's CPU-evaluated FsrEasuF/FsrRcasF.  Steps rotate over a ring of distinct frame sets
-larger than the 256 MiB Infinity Cache, so every step streams from HBM like a video pipeline would.
+the reference's CPU-evaluated FsrEasuF/FsrRcasF.  Steps rotate over a ring of distinct inputs and
+outputs of more than 1 GiB (four times the 256 MiB Infinity Cache), so every step reads its frame from
+HBM and writes its result to HBM like a video pipeline would; the EASU->RCAS intermediary is one
+buffer reused by every step, as the sample's single intermediary texture is.
 Frames are independent, so N GPUs run N independent streams (weak scaling); the only collective is
 the reduction of the throughput counters.  Rank 0 prints ONE JSON line.
 """
@@ -145,7 +147,7 @@ def main():
     ap.add_argument("--graph", type=int, default=0,
                     help="capture this many consecutive steps into one hipGraph and replay it (launch-bound small frames, SURVEY H9); "
                          "--steps is rounded down to a multiple of it")
-    ap.add_argument("--ring", type=int, default=0, help="distinct frame sets to rotate over (0 = enough to exceed 256 MiB)")
+    ap.add_argument("--ring", type=int, default=0, help="distinct input / output sets to rotate over (0 = enough to exceed 1 GiB)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fast-paths", action="store_true", help="FSR1_FLAG_NO_FAST_PATHS: generic kernels only (A/B of the exact-2x variants)")
     args = ap.parse_args()
@@ -181,8 +183,12 @@ def main():
     if args.storage != "rgba16f" and args.math == "h":
         raise SystemExit("--math h (FsrEasuH/FsrRcasH) is defined on RGBA16F images")
     in_bytes, out_bytes = in_w * in_h * px * frames, out_w * out_h * px * frames
-    set_bytes = in_bytes + out_bytes * (2 if args.pipeline == "two-pass" else 1)
-    ring = args.ring or max(2, -(-320 * 2**20 // set_bytes))
+    # Buffer layout of a step: inputs and outputs rotate over `ring` sets that together exceed 1 GiB — four times the 256 MB
+    # Infinity Cache, so every step reads its input from HBM and writes its output to HBM — while the EASU->RCAS intermediary
+    # is ONE buffer reused by every step, as the sample's single intermediary texture is (FSR_Filter.cpp:70-86): for one 4K
+    # frame it stays in the Infinity Cache between the two passes and between steps (DESIGN.md section 5 has the sensitivity:
+    # rotating the intermediary as well costs 2-3 %).
+    ring = args.ring or max(2, -(-(1 << 30) // (in_bytes + out_bytes)))
 
     # synthetic frames: a few distinct numpy frames uploaded once, then varied on-device per ring slot
     def upload(k):
@@ -194,12 +200,12 @@ def main():
         return torch.from_numpy(f).to(device)
 
     base = [upload(k) for k in range(min(frames, 2))]
-    srcs, mids, dsts = [], [], []
+    srcs, dsts = [], []
     for s in range(ring):
         t = torch.stack([torch.roll(base[f % len(base)], shifts=(3 * s + f, 5 * s + 2 * f), dims=(0, 1)) for f in range(frames)])
         srcs.append(t.contiguous())
-        mids.append(torch.empty(frames, out_h, out_w, 4, dtype=tdtype, device=device) if args.pipeline == "two-pass" else None)
         dsts.append(torch.empty(frames, out_h, out_w, 4, dtype=tdtype, device=device))
+    mid = torch.empty(frames, out_h, out_w, 4, dtype=tdtype, device=device) if args.pipeline == "two-pass" else None
     stages = None
     if args.stages:
         g = torch.Generator(device="cpu").manual_seed(1234)
@@ -220,8 +226,8 @@ def main():
     def step(i):
         s = i % ring
         if args.pipeline == "two-pass":
-            fsr.easu(srcs[s], mids[s], con=easu_con, flags=math_flags, stages=pre)
-            fsr.rcas(mids[s], dsts[s], con=rcas_con, flags=math_flags, stages=post)
+            fsr.easu(srcs[s], mid, con=easu_con, flags=math_flags, stages=pre)
+            fsr.rcas(mid, dsts[s], con=rcas_con, flags=math_flags, stages=post)
         elif args.pipeline == "fused":
             fsr.easu_rcas_fused(srcs[s], dsts[s], easu_con=easu_con, rcas_con=rcas_con, flags=math_flags, stages=stages)
         elif args.pipeline == "color":
@@ -305,8 +311,8 @@ def main():
             hflags = fsr.FLAG_MATH_PACKED_FP16
 
             def h_step(i):
-                fsr.easu(srcs[i % ring], mids[i % ring], con=easu_con, flags=hflags)
-                fsr.rcas(mids[i % ring], dsts[i % ring], con=rcas_con, flags=hflags)
+                fsr.easu(srcs[i % ring], mid, con=easu_con, flags=hflags)
+                fsr.rcas(mid, dsts[i % ring], con=rcas_con, flags=hflags)
             for i in range(min(args.warmup, 50)):
                 h_step(i)
             fence()
@@ -334,13 +340,17 @@ def main():
 
     n_k = max(20, min(args.steps, 200))
     kern = {}
+    rcas_cold_ms = None
     if args.pipeline in ("two-pass", "easu"):
-        tgt = mids if args.pipeline == "two-pass" else dsts
         eflags = math_flags | (0 if args.pipeline == "two-pass" else fsr.FLAG_OUTPUT_STREAMING)
-        kern["easu"] = kernel_ms(lambda i: fsr.easu(srcs[i % ring], tgt[i % ring], con=easu_con, flags=eflags,
-                                                    stages=pre if args.pipeline == "two-pass" else stages), n_k)
+        kern["easu"] = kernel_ms(lambda i: fsr.easu(srcs[i % ring], mid if args.pipeline == "two-pass" else dsts[i % ring], con=easu_con,
+                                                    flags=eflags, stages=pre if args.pipeline == "two-pass" else stages), n_k)
     if args.pipeline == "two-pass":
-        kern["rcas"] = kernel_ms(lambda i: fsr.rcas(mids[i % ring], dsts[i % ring], con=rcas_con, flags=math_flags, stages=post), n_k)
+        # as inside the pipeline: the input is the intermediary EASU left behind (for one 4K frame, in the Infinity Cache)
+        kern["rcas"] = kernel_ms(lambda i: fsr.rcas(mid, dsts[i % ring], con=rcas_con, flags=math_flags, stages=post), n_k)
+        if not args.stages and ring >= 4:
+            # and on an image that comes from HBM: an output written ring/2 steps ago (non-temporal stores, > 512 MB of traffic since)
+            rcas_cold_ms = kernel_ms(lambda i: fsr.rcas(dsts[(i + ring // 2) % ring], dsts[i % ring], con=rcas_con, flags=math_flags), n_k)
     if args.pipeline == "fused":
         kern["fused"] = kernel_ms(lambda i: fsr.easu_rcas_fused(srcs[i % ring], dsts[i % ring], easu_con=easu_con, rcas_con=rcas_con,
                                                                 flags=math_flags, stages=stages), n_k)
@@ -358,6 +368,11 @@ def main():
              "frac": round(gbps / HBM_PEAK_GBPS, 4), "traffic": pmc[0],
              "traffic_source": pmc[1], "algorithmic_bytes": alg[name],
              "avg_kernel_us": round(kern[name] * 1e3, 2)}
+        if name == "rcas":
+            r["input"] = "the EASU->RCAS intermediary, one buffer reused by every step (Infinity-Cache resident for a single 4K frame), as inside the pipeline"
+            if rcas_cold_ms:
+                r["cold_input"] = {"avg_kernel_us": round(rcas_cold_ms * 1e3, 2), "frac": round(alg[name] / (rcas_cold_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                                   "note": "the same pass on an image read from HBM"}
         if pmc[3]:
             r["traffic_stale"] = "%s was taken of other kernel sources (source_hash differs): not quoted" % pmc[3]
         if name in ("easu", "fused"):
@@ -384,7 +399,8 @@ def main():
                                "an upper bound on time, measured on other hardware",
             "dtype": "f32" if args.math != "h" else "f16", "data": "synthetic",
             "config": {"workload": "%s: %dx%d -> %dx%d %s, %d frame(s)/step/GPU, %s, math=%s, ring of %d frame sets"
-                                   % (args.workload, in_w, in_h, out_w, out_h, args.storage.upper(), frames, args.pipeline, args.math, ring),
+                                   % (args.workload, in_w, in_h, out_w, out_h, args.storage.upper(), frames, args.pipeline, args.math, ring)
+                                   + (" (inputs / outputs; one reused intermediary)" if args.pipeline == "two-pass" else ""),
                        "source_hash": fsr._lib.source_hash(),
                        "pipeline": args.pipeline, "storage": args.storage, "color_stages": args.stages, "hip_graph_steps": args.graph, "rcas_sharpness_stops": 0.25,
                        "parallelism": "independent frames per GPU, counters-only collective"},

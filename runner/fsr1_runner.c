@@ -5,8 +5,9 @@
  *
  * One process, one host thread per GPU.  Frames are independent (FSR 1.0 keeps no history), so a
  * batch of F frames is sharded in contiguous blocks over the GPUs; every thread uploads its frames once
- * into a RING of frame sets (input, intermediary, output) larger than the 256 MiB Infinity Cache — so that, like a video
- * stream and like bench.py, every step reads its input from HBM rather than from a cache-resident copy — then runs K
+ * into a RING of input / output sets of more than 1 GiB (four times the 256 MiB Infinity Cache) — so that, like a video
+ * stream and like bench.py, every step reads its input from HBM and writes its output to HBM; the EASU -> RCAS intermediary
+ * is one buffer reused by every step, as the sample's single intermediary texture is — then runs K
  * timed steps of  FsrEasuCon -> EASU -> FsrRcasCon -> RCAS  over its block through the C ABI of libfsr1_hip.so, step i
  * on set i % ring, timing with HIP events on its own stream.  The only inter-GPU traffic is one RCCL
  * all-gather of the per-GPU throughput counters {frames, output pixels, device ns} over xGMI; no image
@@ -45,7 +46,7 @@ typedef struct {
   float sharpness;
   uint32_t stages; /* FSR1_COLOR_* */
   float grain;
-  int ring; /* frame sets to rotate over; 0 = enough to exceed the 256 MiB Infinity Cache */
+  int ring; /* input / output sets to rotate over; 0 = enough to exceed 1 GiB (four times the Infinity Cache) */
   int bands; /* 1: one frame per step, split into row bands over the GPUs */
 } options_t;
 
@@ -155,9 +156,10 @@ static int worker_body_bands(worker_t* w) {
   const int rows = y1 - y0;
   const int m0 = y0 > 0 ? y0 - 1 : 0, m1 = y1 < o->out_h ? y1 + 1 : o->out_h;  /* EASU rows the band's RCAS taps read */
   const size_t in_frame = (size_t)o->in_w * o->in_h * 8, pitch = (size_t)o->out_w * 8;
-  int ring = o->ring > 0 ? o->ring : (int)((320u * 1024u * 1024u + in_frame - 1) / in_frame);
+  const size_t band_set = in_frame + pitch * (size_t)(rows > 0 ? rows : 1);
+  int ring = o->ring > 0 ? o->ring : (int)(((size_t)1024u * 1024u * 1024u + band_set - 1) / band_set);
   if (ring < 2) ring = 2;
-  if (ring > 16) ring = 16;
+  if (ring > 64) ring = 64;
   w->ring = ring;
   if (rows > 0) {
     HIP_OK(w, hipMalloc(&w->d_in, in_frame * ring));
@@ -218,17 +220,19 @@ static int worker_body(worker_t* w) {
   if (o->bands) return worker_body_bands(w);
   const int needs_mid = o->pipeline == 0 || o->pipeline == 3;
   const size_t in_frame = (size_t)o->in_w * o->in_h * 8, out_frame = (size_t)o->out_w * o->out_h * 8;
-  const size_t set_bytes = (in_frame + out_frame * (needs_mid ? 2 : 1)) * (size_t)(nf > 0 ? nf : 1);
+  /* inputs and outputs rotate over sets of more than 1 GiB together (four times the Infinity Cache): every step reads its frames
+   * from HBM and writes its results to HBM; the intermediary is one buffer reused by every step, as the sample's is */
+  const size_t set_bytes = (in_frame + out_frame) * (size_t)(nf > 0 ? nf : 1);
   int ring = o->ring;
   if (ring <= 0) {
-    ring = (int)((320u * 1024u * 1024u + set_bytes - 1) / set_bytes);
+    ring = (int)(((size_t)1024u * 1024u * 1024u + set_bytes - 1) / set_bytes);
     if (ring < 2) ring = 2;
   }
   w->ring = ring;
   if (nf > 0) {
     HIP_OK(w, hipMalloc(&w->d_in, in_frame * nf * ring));
     HIP_OK(w, hipMalloc(&w->d_out, out_frame * nf * ring));
-    if (needs_mid) HIP_OK(w, hipMalloc(&w->d_mid, out_frame * nf * ring));
+    if (needs_mid) HIP_OK(w, hipMalloc(&w->d_mid, out_frame * nf));
     uint16_t* host = (uint16_t*)malloc(in_frame);
     if (!host) { snprintf(w->error, sizeof w->error, "out of host memory"); w->status = -1; return -1; }
     for (int s = 0; s < ring; ++s)
@@ -277,7 +281,7 @@ static int worker_body(worker_t* w) {
       if (i == 0) HIP_OK(w, hipEventRecord(w->ev0, stream));
       const size_t s = (size_t)((i + o->warmup) % ring) * (size_t)nf;
       fsr1_image in = {(char*)w->d_in + in_frame * s, o->in_w, o->in_h, FSR1_FORMAT_RGBA16F, nf, 0, 0};
-      fsr1_image mid = {w->d_mid ? (char*)w->d_mid + out_frame * s : NULL, o->out_w, o->out_h, FSR1_FORMAT_RGBA16F, nf, 0, 0};
+      fsr1_image mid = {w->d_mid, o->out_w, o->out_h, FSR1_FORMAT_RGBA16F, nf, 0, 0};
       fsr1_image out = {(char*)w->d_out + out_frame * s, o->out_w, o->out_h, FSR1_FORMAT_RGBA16F, nf, 0, 0};
       stages.frame = (uint32_t)(i < 0 ? 0 : i); /* the grain / dither pattern changes every frame (ffx_fsr1.h:1006) */
       FSR_OK(w, fsr1_upscale_ex(&in, w->d_mid ? &mid : NULL, &out, &p, &stages, stream));
@@ -323,7 +327,7 @@ static void usage(void) {
   puts("usage: fsr1_runner [--gpus N] [--frames F] [--in WxH] [--out WxH] [--steps K] [--warmup W]\n"
        "                   [--pipeline two-pass|fused|easu|auto] [--math f|exact|h] [--sharpness STOPS] [--hdr]\n"
        "                   [--stages BITS] [--grain AMOUNT]   (colour stages: 1 SRTM, 2 grain, 4 SRTM inverse, 8/16 TEPD 8/10-bit)\n"
-       "                   [--ring R]   (frame sets to rotate over; default: enough to exceed the 256 MiB Infinity Cache)\n"
+       "                   [--ring R]   (input / output sets to rotate over; default: more than 1 GiB, 4 x the Infinity Cache)\n"
        "                   [--bands]    (one frame stream split into row bands over the GPUs instead of frames per GPU)\n"
        "defaults: 1 GPU, 1 frame per GPU, 1920x1080 -> 3840x2160, 100 steps, 10 warmup, two-pass, f, 0.25 stops");
 }

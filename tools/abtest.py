@@ -4,8 +4,8 @@
   python tools/abtest.py --libs variants/a.so,variants/b.so --workloads 1080p_to_4k,1440p_to_4k --reps 3
 
 Each variant runs in its own process (FSR1_HIP_LIB selects the library); per workload it prints one line with the
-HIP-event time per launch (C-ABI stopwatch on the launch stream) of EASU, RCAS on a cold ring, the two-dispatch pair,
-and the fused launch.  Variants are interleaved `reps` times so that box-to-box / thermal drift shows as spread
+HIP-event time per launch (C-ABI stopwatch on the launch stream) of EASU, RCAS on the reused intermediary (`rcas`) and on an
+image read from HBM (`rcas_cold`), the two-dispatch pair, and the fused launch — bench.py's buffer layout.  Variants are interleaved `reps` times so that box-to-box / thermal drift shows as spread
 between repetitions rather than as a difference between variants.
 """
 import argparse
@@ -32,20 +32,20 @@ def child(args):
     timer = fsr.Timer()
     for wl in args.workloads.split(","):
         in_w, in_h, out_w, out_h, frames = bench.WORKLOADS[wl]
-        set_bytes = (in_w * in_h + 2 * out_w * out_h) * 8 * frames
-        ring = max(2, -(-320 * 2**20 // set_bytes))
+        # bench.py's layout: inputs / outputs rotate over > 1 GiB, the intermediary is one reused buffer
+        ring = max(2, -(-(1 << 30) // ((in_w * in_h + out_w * out_h) * 8 * frames)))
         base = torch.from_numpy(fsr.frames.synthetic_frame(in_w, in_h, k=1)).to(dev)
         srcs = [torch.stack([torch.roll(base, shifts=(3 * s + f, 5 * s + 2 * f), dims=(0, 1)) for f in range(frames)]).contiguous() for s in range(ring)]
-        mids = [torch.empty(frames, out_h, out_w, 4, dtype=torch.float16, device=dev) for _ in range(ring)]
+        mid = torch.empty(frames, out_h, out_w, 4, dtype=torch.float16, device=dev)
         dsts = [torch.empty(frames, out_h, out_w, 4, dtype=torch.float16, device=dev) for _ in range(ring)]
         econ = fsr.FsrEasuCon(in_w, in_h, in_w, in_h, out_w, out_h)
         rcon = fsr.FsrRcasCon(0.25)
-        for s in range(ring):
-            fsr.easu(srcs[s], mids[s], con=econ, flags=flags)
+        fsr.easu(srcs[0], mid, con=econ, flags=flags)
         torch.cuda.synchronize()
 
-        def easu(i): fsr.easu(srcs[i % ring], mids[i % ring], con=econ, flags=flags)
-        def rcas(i): fsr.rcas(mids[i % ring], dsts[i % ring], con=rcon, flags=flags)
+        def easu(i): fsr.easu(srcs[i % ring], mid, con=econ, flags=flags)
+        def rcas(i): fsr.rcas(mid, dsts[i % ring], con=rcon, flags=flags)
+        def rcas_cold(i): fsr.rcas(dsts[(i + ring // 2) % ring], dsts[i % ring], con=rcon, flags=flags)  # an image read from HBM
         def pair(i): easu(i); rcas(i)
         def fused(i): fsr.easu_rcas_fused(srcs[i % ring], dsts[i % ring], easu_con=econ, rcas_con=rcon, flags=flags)
 
@@ -66,11 +66,11 @@ def child(args):
 
         n = max(10, int(args.launches / max(1, frames)))
         row = {"lib": os.path.basename(os.environ.get("FSR1_HIP_LIB", "default")), "workload": wl, "math": args.math}
-        for name, fn in (("easu", easu), ("rcas", rcas), ("pair", pair), ("fused", fused)):
+        for name, fn in (("easu", easu), ("rcas", rcas), ("rcas_cold", rcas_cold), ("pair", pair), ("fused", fused)):
             if name in args.kernels.split(","):
                 row[name + "_us"] = round(ms(fn, n) * 1e3, 2)
         print(json.dumps(row), flush=True)
-        del srcs, mids, dsts
+        del srcs, mid, dsts
         torch.cuda.empty_cache()
 
 
