@@ -149,6 +149,8 @@ def main():
                          "--steps is rounded down to a multiple of it")
     ap.add_argument("--ring", type=int, default=0, help="distinct input / output sets to rotate over (0 = enough to exceed 1 GiB)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cold-rcas", action="store_true",
+                    help="skip the extra RCAS launches on an HBM-cold image (profiling runs: keeps rocprofv3's per-kernel average to the pipeline's own launches)")
     ap.add_argument("--no-fast-paths", action="store_true", help="FSR1_FLAG_NO_FAST_PATHS: generic kernels only (A/B of the exact-2x variants)")
     args = ap.parse_args()
 
@@ -348,7 +350,7 @@ def main():
     if args.pipeline == "two-pass":
         # as inside the pipeline: the input is the intermediary EASU left behind (for one 4K frame, in the Infinity Cache)
         kern["rcas"] = kernel_ms(lambda i: fsr.rcas(mid, dsts[i % ring], con=rcas_con, flags=math_flags, stages=post), n_k)
-        if not args.stages and ring >= 4:
+        if not args.stages and ring >= 4 and not args.no_cold_rcas:
             # and on an image that comes from HBM: an output written ring/2 steps ago (non-temporal stores, > 512 MB of traffic since)
             rcas_cold_ms = kernel_ms(lambda i: fsr.rcas(dsts[(i + ring // 2) % ring], dsts[i % ring], con=rcas_con, flags=math_flags), n_k)
     if args.pipeline == "fused":
