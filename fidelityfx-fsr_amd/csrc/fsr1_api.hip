@@ -19,6 +19,10 @@ void rcas_geometry(int width, int height, int frames, int* tiles_x, int* tiles_y
 hipError_t fused_launch(const FusedArgs& a, int fmt, bool exact, hipStream_t stream);
 size_t fused_lds_bytes(int fmt, int fp_w, int fp_h);
 hipError_t fused_h_launch(const FusedArgs& a, hipStream_t stream);
+hipError_t fused_s2_launch(const FusedArgs& a, int fmt, bool exact, hipStream_t stream);
+size_t fused_s2_lds_bytes(int fmt, int qh);
+void fused_s2_geometry(int width, int height, int qh, int* tiles_x, int* tiles_y);
+int fused_s2_quad_rows();
 size_t fused_h_lds_bytes(int fp_w, int fp_h);
 hipError_t easu_h_launch(const EasuArgs& a, bool s2, hipStream_t stream);
 hipError_t easu_color_launch(const EasuArgs& a, int fin, int fout, bool exact, hipStream_t stream);
@@ -442,11 +446,18 @@ static int fused_dispatch_impl(const fsr1_image* in, const fsr1_image* out, cons
   a.tiles_x = (out->width + kTileW - 1) / kTileW;
   a.tiles_y = (out->height + kFusedTileH - 1) / kFusedTileH;
   a.frames = out->frames;
+  // Exact 2x (con0 = {1/2, 1/2, -1/4, -1/4}), plain F arithmetic, a whole image: the variant whose lanes own 2x2 quads
+  // of the apron tile (fsr1_fused_s2.hip); its tiles are 62 pixels wide and 2 QH - 2 tall.
+  const bool s2 = easu_con[0] == 0x3f000000u && easu_con[1] == 0x3f000000u && easu_con[2] == 0xbe800000u && easu_con[3] == 0xbe800000u &&
+                  !(flags & FSR1_FLAG_NO_FAST_PATHS) && !packed && !a.color.stages && !origin_y && !rows_above && !rows_below &&
+                  fused_s2_lds_bytes(in->format, fused_s2_quad_rows()) <= 160 * 1024;
+  if (s2) fused_s2_geometry(out->width, out->height, fused_s2_quad_rows(), &a.tiles_x, &a.tiles_y);
   if ((rc = check_grid("fused", a.tiles_x, a.tiles_y, a.frames))) return rc;
   a.flags = resolve_output_policy(flags, true);
   const bool exact = (flags & FSR1_FLAG_MATH_EXACT) != 0;
   hipError_t e = packed ? fused_h_launch(a, static_cast<hipStream_t>(stream))
                  : a.color.stages ? fused_color_launch(a, in->format, out->format, exact, static_cast<hipStream_t>(stream))
+                 : s2             ? fused_s2_launch(a, in->format, exact, static_cast<hipStream_t>(stream))
                                   : fused_launch(a, in->format, exact, static_cast<hipStream_t>(stream));
   if (e != hipSuccess) return hip_fail(e, "fused launch");
   return FSR1_OK;
@@ -515,9 +526,13 @@ int fsr1_upscale_ex(const fsr1_image* in, const fsr1_image* intermediary, const 
   FsrRcasCon(rcas_con, p->rcas_attenuation);  // :124
   const uint32_t rcas_flags = math | rcas_opts | out_policy | (p->hdr ? FSR1_FLAG_HDR_SQUARE : 0u);  // :125 Sample.x = hdr
   bool fused = p->fused == 1;
-  if (p->fused == 2) {  // auto, on round-2 measurements: the fused launch pays off only where a frame is launch-bound
+  if (p->fused == 2) {
+    // auto, on round-2 measurements: at exactly 2x the quad form of the fused launch (fsr1_fused_s2.hip) beats
+    // the two dispatches at every size; elsewhere the fused launch pays off only where a frame is launch-bound
     const long long out_pixels = (long long)out->width * (long long)out->height * (long long)out->frames;
-    fused = !intermediary || out_pixels <= 3000000ll;
+    const bool quad_form = easu_con[0] == 0x3f000000u && easu_con[1] == 0x3f000000u && easu_con[2] == 0xbe800000u && easu_con[3] == 0xbe800000u &&
+                           !(math & (FSR1_FLAG_MATH_PACKED_FP16 | FSR1_FLAG_NO_FAST_PATHS)) && !stages;
+    fused = !intermediary || quad_form || out_pixels <= 3000000ll;
   } else if (p->fused != 0 && p->fused != 1) {
     return fail(FSR1_ERR_INVALID_ARGUMENT, "upscale: params.fused must be 0, 1 or 2 (auto)");
   }

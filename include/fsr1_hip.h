@@ -233,12 +233,13 @@ typedef struct fsr1_params {
   float rcas_attenuation;              /* pState->rcasAttenuation, stops (sample default 0.25, SampleRenderer.h:49) */
   int32_t hdr;                         /* `hdr` argument of Upscale: Sample.x = hdr && !use_rcas for EASU, hdr for RCAS */
   int32_t fused;                       /* 0: EASU + RCAS as two dispatches; 1: the single fused launch (needs use_rcas);
-                                          2: whichever is faster on MI355X, decided on round-2 measurements: the two
-                                          dispatches whenever the launch has more than 3 Mpixel of output (4K, 2.0x:
-                                          66.8 vs 72.3 us; 1.5x: 80.7 vs 88.8), the fused launch below that, where a
-                                          frame is launch-bound (1080p output: 22.7 vs 28.2 us), for every arithmetic
-                                          (FSR1_FLAG_MATH_PACKED_FP16 has a fused launch too); with intermediary == NULL it
-                                          is the fused launch */
+                                          2: whichever is faster on MI355X, decided on round-2 measurements: at exactly
+                                          2x with F arithmetic and no colour stages the fused launch, whose quad form wins
+                                          at every size (4K: 63 vs 67 us; 8K x16: 3.90 vs 4.08 ms; 1440p: 31 vs 38 us);
+                                          otherwise the two dispatches whenever the launch has more than 3 Mpixel of output
+                                          (4K at 1.5x: 80.7 vs 88.8 us) and the fused launch below that, where a frame is
+                                          launch-bound, for every arithmetic (FSR1_FLAG_MATH_PACKED_FP16 has a fused launch
+                                          too); with intermediary == NULL it is the fused launch */
   uint32_t flags;                      /* FSR1_FLAG_MATH_*, FSR1_FLAG_RCAS_DENOISE / _PASSTHROUGH_ALPHA, FSR1_FLAG_OUTPUT_* (of the pass that writes `out`) */
 } fsr1_params;
 

@@ -435,10 +435,12 @@ def test_exact_2x_fast_path_is_bit_identical(fsr, shape, fmt):
 
 
 def test_upscale_auto_pipeline(fsr, port):
-    """fsr1_params.fused = 2 picks the fused launch where a frame is launch-bound (<= 3 Mpixel of output per launch) and the
-    two dispatches above (round-2 measurements, include/fsr1_hip.h); the image is the same either way (fused == two-pass
-    bit for bit), so only the choice itself needs checking: the intermediary is written iff two-pass ran."""
-    for (iw, ih, ow, oh), expect_two_pass in (((160, 90, 320, 180), False), ((160, 90, 240, 135), False), ((1280, 720, 2560, 1440), True)):
+    """fsr1_params.fused = 2 picks the fused launch at exactly 2x (its quad form wins at every size) and, at other ratios, where
+    a frame is launch-bound (<= 3 Mpixel of output per launch), the two dispatches above (round-2 measurements,
+    include/fsr1_hip.h); the image is the same either way (fused == two-pass bit for bit), so only the choice itself needs
+    checking: the intermediary is written iff two-pass ran."""
+    for (iw, ih, ow, oh), expect_two_pass in (((160, 90, 320, 180), False), ((160, 90, 240, 135), False), ((1280, 720, 2560, 1440), False),
+                                              ((1707, 960, 2560, 1440), True)):
         src = dev(frames.synthetic_frame(iw, ih, k=2, dtype=np.float16))
         dst = torch.zeros(oh, ow, 4, dtype=torch.float16, device="cuda")
         filt = fsr.FSR_Filter()
@@ -552,3 +554,38 @@ def test_output_store_policy_does_not_change_pixels(fsr):
         for other in outs[1:]:
             for a, b in zip(outs[0], other):
                 assert torch.equal(a.view(torch.int16), b.view(torch.int16))
+
+
+@pytest.mark.parametrize("shape", [(31, 7), (32, 8), (30, 6), (31, 8), (63, 15), (62, 14), (1, 1), (2, 3), (100, 50), (125, 29)], ids=lambda s: "%dx%d" % s)
+def test_fused_exact_2x_quad_form(fsr, shape):
+    """fsr1_fused_s2.hip (62 x 14 output tiles, quads of the 64 x 16 apron tile, DPP-only RCAS neighbours) against the generic
+    fused kernel (FSR1_FLAG_NO_FAST_PATHS) and the two dispatches, at sizes on and around its tile boundaries, for every storage
+    format, both arithmetics, the RCAS options, batches and padded rows: bit-identical."""
+    iw, ih = shape
+    ow, oh = 2 * iw, 2 * ih
+    n = 3
+    base = np.stack([frames.synthetic_frame(iw, ih, k=20 + f, dtype=np.float16) for f in range(n)])
+    for dt in (torch.float16, torch.float32, torch.uint8):
+        if dt == torch.uint8:
+            src_c = (dev(base).float().clamp(0, 1) * 255 + 0.5).floor().to(torch.uint8)
+        else:
+            src_c = dev(base).to(dt)
+        big_in = torch.zeros(n, ih + 2, iw + 3, 4, dtype=dt, device="cuda")
+        src = big_in[:, :ih, :iw]
+        src.copy_(src_c)
+        for flags in (0, fsr.FLAG_MATH_EXACT, fsr.FLAG_RCAS_DENOISE | fsr.FLAG_RCAS_PASSTHROUGH_ALPHA, fsr.FLAG_MATH_EXACT | fsr.FLAG_HDR_SQUARE):
+            outs = []
+            for extra in (0, fsr.FLAG_NO_FAST_PATHS):
+                big_out = torch.full((n, oh + 1, ow + 5, 4), 7, dtype=dt, device="cuda")
+                dst = big_out[:, :oh, :ow]
+                fsr.easu_rcas_fused(src, dst, sharpness=0.3, flags=flags | extra)
+                torch.cuda.synchronize()
+                assert bool((big_out[:, oh:] == 7).all()) and bool((big_out[:, :, ow:] == 7).all()), "wrote outside the output view"
+                outs.append(dst.clone())
+            mid = torch.zeros(n, oh, ow, 4, dtype=dt, device="cuda")
+            two = torch.zeros_like(mid)
+            fsr.easu(src, mid, flags=flags & (fsr.FLAG_MATH_EXACT))
+            fsr.rcas(mid, two, sharpness=0.3, flags=flags)
+            raw = {torch.float16: torch.int16, torch.float32: torch.int32, torch.uint8: torch.uint8}[dt]
+            assert torch.equal(outs[0].view(raw), outs[1].view(raw)), "quad form != generic fused (%s, flags %d)" % (dt, flags)
+            assert torch.equal(outs[0].view(raw), two.view(raw)), "quad form != two dispatches (%s, flags %d)" % (dt, flags)
