@@ -83,7 +83,8 @@ def pmc_traffic(fsr, workload, pipeline, kernel_name, math="f", storage="rgba16f
         if d.get("workload") != workload or d.get("pipeline") != pipeline or d.get("math", "f") != math or d.get("storage", "rgba16f") != storage:
             continue
         for k, v in d.get("kernels", {}).items():
-            if ("::%s%s_kernel<" % (kernel_name, "_h" if math == "h" else "")) in k + "<" and "traffic_bytes" in v.get("hbm_per_launch", {}):
+            names = ["::%s%s_kernel<" % (kernel_name, "_h" if math == "h" else "")] + (["::fused_s2_kernel<"] if kernel_name == "fused" else [])
+            if any(nm in k + "<" for nm in names) and "traffic_bytes" in v.get("hbm_per_launch", {}):
                 if d.get("source_hash") != now:
                     stale = os.path.relpath(f, ROOT)
                     continue

@@ -20,7 +20,7 @@ for f in sorted(glob.glob(os.path.join(ROOT, "profiles", tag + "_*.line"))):
         if kind not in line["kernels"]:
             return "—"
         for k, v in prof["kernels"].items():
-            if want in k:
+            if want in k or (kind == "fused" and "::fused_s2_kernel<" in k):
                 alg = line["kernels"][kind]["algorithmic_bytes"]
                 return "%.1f (%.2f)" % (v["avg_us"], alg / (v["avg_us"] * 1e-6) / 8e12)
         return "—"
