@@ -360,6 +360,17 @@ def main():
     if args.pipeline == "color":
         kern["color"] = kernel_ms(lambda i: fsr.color(srcs[i % ring], dsts[i % ring], stages, flags=math_flags), n_k)
 
+    if also and "fused" in also:
+        # the single launch as a kernel: HIP-event time per launch, its algorithmic bytes (in + out) against the HBM line, and
+        # the PMC traffic / VALU count of its own committed profile when that was taken of the running sources
+        tf_ms = kernel_ms(lambda i: fsr.easu_rcas_fused(srcs[i % ring], dsts[i % ring], easu_con=easu_con, rcas_con=rcas_con, flags=math_flags), n_k)
+        fpmc = pmc_traffic(fsr, args.workload, "fused", "fused", args.math, args.storage) if not args.no_fast_paths else (None, None, None, None)
+        also["fused"].update({"avg_kernel_us": round(tf_ms * 1e3, 2), "algorithmic_bytes": in_bytes + out_bytes,
+                              "hbm_frac": round((in_bytes + out_bytes) / (tf_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                              "traffic": fpmc[0], "traffic_source": fpmc[1]})
+        if fpmc[2]:
+            also["fused"]["valu_frac"] = round(fpmc[2] / (tf_ms * 1e-3) / 1e9 / VALU_PEAK_GINST, 4)
+
     # algorithmic HBM bytes per launch: EASU in+out, RCAS 2*out, fused in+out
     alg = {"easu": in_bytes + out_bytes, "rcas": 2 * out_bytes, "fused": in_bytes + out_bytes, "color": 2 * out_bytes}
     dominant = max(kern, key=kern.get)
