@@ -2,7 +2,9 @@
 """Headline benchmark: upscaled megapixels/s of the FSR 1.0 hot path (EASU + RCAS) on MI355X.
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
+  N > 1, either launch style gives the same run and ONE JSON line:
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+    python bench.py --gpus N ...      (no WORLD_SIZE in the environment: bench.py starts the N ranks itself, the same way)
 
 A "step" is one pass of the hot path over one batch of synthetic frames that are already resident
 in HBM.  Default workload = BASELINE.json configs[1]: 1920x1080 -> 3840x2160, EASU + RCAS, RGBA16F
@@ -63,6 +65,75 @@ def reduce_counters(frames, pixels, seconds, device):
     dist.all_reduce(s, op=dist.ReduceOp.SUM)
     dist.all_reduce(m, op=dist.ReduceOp.MAX)
     return {"frames": int(round(s[0].item())), "pixels": int(round(s[1].item())), "seconds": float(m[0].item())}
+
+
+def gather_seconds(seconds, device):
+    """Every rank's own time for its K steps, in rank order (one more counters-only collective)."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return [float(seconds)]
+    mine = torch.tensor([float(seconds)], dtype=torch.float64, device=device)
+    out = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, mine)
+    return [float(t.item()) for t in out]
+
+
+def self_launch(argv, n):
+    """`python bench.py --gpus N` with no WORLD_SIZE in the environment: start the N ranks the way the driver's other launch
+    style does — python -m torch.distributed.run --nnodes=1 --nproc-per-node N on 127.0.0.1 — and hand back its exit code.
+    Rank 0's JSON line reaches this process's stdout unchanged (torchrun passes the workers' stdout through)."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, FSR1_BENCH_SELF_LAUNCHED="1", MASTER_ADDR="127.0.0.1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL across processes needs it on these hosts
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    return subprocess.call(cmd, env=env)
+
+
+def stub_main(args, world, rank):
+    """--stub: the multi-rank plumbing of this file with no GPU and no kernel — rendezvous, barriers, K "steps" of 1 ms of
+    sleep, the counters-only collectives, rank 0's JSON line — over gloo on CPU.  A test fixture (tests/test_shard.py): the
+    line says data = "stub" and carries no roofline."""
+    import torch
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+    device = torch.device("cpu")
+    in_w, in_h, out_w, out_h, frames = WORKLOADS[args.workload]
+    for _ in range(args.warmup):
+        pass
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(1e-3)
+    seconds = time.perf_counter() - t0
+    if world > 1:
+        dist.barrier()
+    total = reduce_counters(frames * args.steps, frames * args.steps * out_w * out_h, seconds, device)
+    per_rank = gather_seconds(seconds, device)
+    if rank == 0:
+        print(json.dumps({"metric": "stub (no GPU work): plumbing of bench.py --gpus N", "value": round(total["pixels"] / total["seconds"] / 1e6, 1),
+                          "unit": "Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(total["seconds"] * 1e3 / args.steps, 5), "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": "none", "data": "stub",
+                          "config": {"workload": args.workload, "launch": launch_style(), "collective_backend": "gloo" if world > 1 else None,
+                                     "world_size_seen": dist.get_world_size() if world > 1 else 1, "frames_total": total["frames"]},
+                          "per_rank_seconds": [round(t, 6) for t in per_rank]}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def launch_style():
+    if os.environ.get("FSR1_BENCH_SELF_LAUNCHED") == "1":
+        return "self-launched: python bench.py --gpus N started torch.distributed.run itself"
+    return "torch.distributed.run" if "WORLD_SIZE" in os.environ else "single process"
 
 
 def pmc_traffic(fsr, workload, pipeline, kernel_name, math="f", storage="rgba16f"):
@@ -153,7 +224,29 @@ def main():
     ap.add_argument("--no-cold-rcas", action="store_true",
                     help="skip the extra RCAS launches on an HBM-cold image (profiling runs: keeps rocprofv3's per-kernel average to the pipeline's own launches)")
     ap.add_argument("--no-fast-paths", action="store_true", help="FSR1_FLAG_NO_FAST_PATHS: generic kernels only (A/B of the exact-2x variants)")
+    ap.add_argument("--rotate-intermediary", action="store_true",
+                    help="two-pass: rotate the EASU->RCAS intermediary over the ring as well (round 1's method; default: one reused buffer, as the sample has)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process group of the counters-only collectives: nccl (= RCCL over xGMI, the product path) or gloo (host; for boxes "
+                         "with fewer GPUs than ranks, see --oversubscribe)")
+    ap.add_argument("--oversubscribe", action="store_true",
+                    help="with --backend gloo: let ranks share GPUs (rank r runs on device r %% visible devices) — exercises the N-rank launch on a one-GPU box; "
+                         "the line says so and its value is not a scaling figure")
+    ap.add_argument("--stub", action="store_true", help="test fixture: the N-rank plumbing over gloo with no GPU work (data = 'stub')")
     args = ap.parse_args()
+
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if os.environ.get("WORLD_SIZE", "1") == "1" and args.gpus > 1 and os.environ.get("FSR1_BENCH_SELF_LAUNCHED") != "1":
+        # started like `--gpus 1` is: one bare python process.  Start the ranks ourselves, exactly as the other launch style does.
+        raise SystemExit(self_launch(sys.argv[1:], args.gpus))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
+    if args.stub:
+        return stub_main(args, world, rank)
 
     import numpy as np
     import torch
@@ -162,20 +255,22 @@ def main():
     fsr = importlib.import_module("fidelityfx-fsr_amd")
     fsr.load()  # raises if the HIP library is not built: no fallback
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
-        raise SystemExit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the FSR1 HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    n_dev = torch.cuda.device_count()
+    if local_rank >= n_dev and not (args.oversubscribe and args.backend == "gloo"):
+        raise SystemExit("rank %d has no GPU: %d visible device(s) for --gpus %d (one process per GPU; "
+                         "--backend gloo --oversubscribe shares devices for a plumbing run)" % (local_rank, n_dev, args.gpus))
+    dev_index = local_rank % n_dev
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)  # "nccl" is RCCL on ROCm
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)  # "nccl" is RCCL on ROCm
+        else:
+            dist.init_process_group("gloo")
+    coll_device = device if args.backend == "nccl" else torch.device("cpu")
 
     in_w, in_h, out_w, out_h, frames = WORKLOADS[args.workload]
     math_flags = {"f": 0, "exact": fsr.FLAG_MATH_EXACT, "h": fsr.FLAG_MATH_PACKED_FP16}[args.math]
@@ -208,7 +303,9 @@ def main():
         t = torch.stack([torch.roll(base[f % len(base)], shifts=(3 * s + f, 5 * s + 2 * f), dims=(0, 1)) for f in range(frames)])
         srcs.append(t.contiguous())
         dsts.append(torch.empty(frames, out_h, out_w, 4, dtype=tdtype, device=device))
-    mid = torch.empty(frames, out_h, out_w, 4, dtype=tdtype, device=device) if args.pipeline == "two-pass" else None
+    mids = [torch.empty(frames, out_h, out_w, 4, dtype=tdtype, device=device) for _ in range(ring if args.rotate_intermediary else 1)] \
+        if args.pipeline == "two-pass" else [None]
+    mid = mids[0]
     stages = None
     if args.stages:
         g = torch.Generator(device="cpu").manual_seed(1234)
@@ -229,8 +326,9 @@ def main():
     def step(i):
         s = i % ring
         if args.pipeline == "two-pass":
-            fsr.easu(srcs[s], mid, con=easu_con, flags=math_flags, stages=pre)
-            fsr.rcas(mid, dsts[s], con=rcas_con, flags=math_flags, stages=post)
+            m = mids[s % len(mids)]
+            fsr.easu(srcs[s], m, con=easu_con, flags=math_flags, stages=pre)
+            fsr.rcas(m, dsts[s], con=rcas_con, flags=math_flags, stages=post)
         elif args.pipeline == "fused":
             fsr.easu_rcas_fused(srcs[s], dsts[s], easu_con=easu_con, rcas_con=rcas_con, flags=math_flags, stages=stages)
         elif args.pipeline == "color":
@@ -289,7 +387,8 @@ def main():
             step(args.warmup + i)
         seconds = close() - t0
 
-    total = reduce_counters(frames * args.steps, frames * args.steps * out_w * out_h, seconds, device)
+    total = reduce_counters(frames * args.steps, frames * args.steps * out_w * out_h, seconds, coll_device)
+    per_rank_seconds = gather_seconds(seconds, coll_device)
     value = total["pixels"] / total["seconds"] / 1e6
 
     # The single-launch pipeline (BASELINE configs[3]) writes the very same image as the two dispatches
@@ -305,7 +404,7 @@ def main():
         t0 = time.perf_counter()
         for i in range(args.steps):
             fused_step(i)
-        tf = reduce_counters(frames * args.steps, frames * args.steps * out_w * out_h, close() - t0, device)
+        tf = reduce_counters(frames * args.steps, frames * args.steps * out_w * out_h, close() - t0, coll_device)
         also = {"fused": {"value": round(tf["pixels"] / tf["seconds"] / 1e6, 1), "unit": "Mpix/s",
                           "ms_per_step": round(tf["seconds"] * 1e3 / args.steps, 5),
                           "note": "EASU->RCAS in one launch, output bit-identical to the two dispatches (BASELINE configs[3])"}}
@@ -322,7 +421,24 @@ def main():
             t0 = time.perf_counter()
             for i in range(args.steps):
                 h_step(i)
-            th = reduce_counters(frames * args.steps, frames * args.steps * out_w * out_h, close() - t0, device)
+            th = reduce_counters(frames * args.steps, frames * args.steps * out_w * out_h, close() - t0, coll_device)
+            # and the bit-exact arithmetic (FSR1_FLAG_MATH_EXACT: the reference's operation order, no re-association): what
+            # bit-identity with the CPU-evaluated FsrEasuF / FsrRcasF costs against the default (<= 1 ULP) arithmetic
+            eflags_x = fsr.FLAG_MATH_EXACT
+
+            def x_step(i):
+                fsr.easu(srcs[i % ring], mid, con=easu_con, flags=eflags_x)
+                fsr.rcas(mid, dsts[i % ring], con=rcas_con, flags=eflags_x)
+            for i in range(min(args.warmup, 50)):
+                x_step(i)
+            fence()
+            t0 = time.perf_counter()
+            for i in range(args.steps):
+                x_step(i)
+            tx = reduce_counters(frames * args.steps, frames * args.steps * out_w * out_h, close() - t0, coll_device)
+            also["exact_two_pass"] = {"value": round(tx["pixels"] / tx["seconds"] / 1e6, 1), "unit": "Mpix/s",
+                                      "ms_per_step": round(tx["seconds"] * 1e3 / args.steps, 5),
+                                      "note": "FSR1_FLAG_MATH_EXACT: bit-identical to the CPU-evaluated FsrEasuF + FsrRcasF (0 differing values on whole frames)"}
             also["packed_fp16_two_pass"] = {"value": round(th["pixels"] / th["seconds"] / 1e6, 1), "unit": "Mpix/s",
                                             "ms_per_step": round(th["seconds"] * 1e3 / args.steps, 5),
                                             "note": "FsrEasuH + FsrRcasH (parity class H: bit-exact vs the reference's packed-fp16 path; "
@@ -380,6 +496,9 @@ def main():
         pmc = pmc_traffic(fsr, args.workload, args.pipeline, name, args.math, args.storage) if not args.stages and not args.no_fast_paths else (None, None, None, None)
         r = {"kernel": name, "bound": "hbm", "achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
              "frac": round(gbps / HBM_PEAK_GBPS, 4), "traffic": pmc[0],
+             # PMC counters cannot be read inside the timed run: the figure is looked up in the committed rocprofv3 summary of
+             # this configuration, and only when that summary was taken of the kernel sources running now (source_hash)
+             "traffic_kind": "profile-lookup" if pmc[0] is not None else None,
              "traffic_source": pmc[1], "algorithmic_bytes": alg[name],
              "avg_kernel_us": round(kern[name] * 1e3, 2)}
         if name == "rcas":
@@ -404,7 +523,8 @@ def main():
     if rank == 0:
         line = {
             "metric": {"easu": "upscaled megapixels/sec (EASU only)", "color": "megapixels/sec (colour pass)"}.get(
-                args.pipeline, "upscaled megapixels/sec (EASU+RCAS, %s fp16)" % ("1080p->4K" if args.workload == "1080p_to_4k" else args.workload)),
+                args.pipeline, "upscaled megapixels/sec (EASU+RCAS, %s %s)" % ("1080p->4K" if args.workload == "1080p_to_4k" else args.workload,
+                                                                                  {"rgba16f": "fp16", "rgba8": "rgba8 unorm", "rgba32f": "fp32 storage"}[args.storage])),
             "value": round(value, 1), "unit": "Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(total["seconds"] * 1e3 / args.steps, 5), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": (round(value / world / {(3840, 2160): PUBLISHED_4K_MPIX_S, (2560, 1440): PUBLISHED_1440P_MPIX_S}[(out_w, out_h)], 2)
@@ -416,8 +536,15 @@ def main():
                                    % (args.workload, in_w, in_h, out_w, out_h, args.storage.upper(), frames, args.pipeline, args.math, ring)
                                    + (" (inputs / outputs; one reused intermediary)" if args.pipeline == "two-pass" else ""),
                        "source_hash": fsr._lib.source_hash(),
+                       "intermediary": None if args.pipeline != "two-pass" else ("rotated" if args.rotate_intermediary else "reused"),
+                       "launch": launch_style(), "world_size_seen": dist.get_world_size() if world > 1 else 1,
+                       "collective_backend": (("rccl (torch.distributed 'nccl')" if args.backend == "nccl" else "gloo") if world > 1 else None),
+                       "devices_visible": n_dev, "oversubscribed": bool(world > n_dev),
+                       "k_dependence": "the timed region is host-clocked around K steps: at the driver's K = 20 (1.4 ms) the first launch's latency and the "
+                                       "closing synchronize are 4-6 % of it (round 2: 117.7 Gpix/s at K = 20, 122-126 at K >= 300 on the same kernels)",
                        "pipeline": args.pipeline, "storage": args.storage, "color_stages": args.stages, "hip_graph_steps": args.graph, "rcas_sharpness_stops": 0.25,
                        "parallelism": "independent frames per GPU, counters-only collective"},
+            "per_rank_seconds": [round(t, 6) for t in per_rank_seconds],
             "roofline": roof(dominant),
             "kernels": {k: roof(k) for k in kern},
             "pipeline_hbm": {"algorithmic_bytes_per_step": sum(alg[k] for k in kern),

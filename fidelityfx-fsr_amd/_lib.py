@@ -73,6 +73,7 @@ SYMBOLS = {
     "fsr1_easu_rcas_fused_dispatch_ex": (ctypes.c_int, [_IMG, _IMG, _U32P, _U32P, ctypes.c_uint32, _STG, ctypes.c_void_p]),
     "fsr1_upscale": (ctypes.c_int, [ctypes.POINTER(fsr1_image)] * 3 + [ctypes.POINTER(fsr1_params), ctypes.c_void_p]),
     "fsr1_upscale_ex": (ctypes.c_int, [_IMG] * 3 + [ctypes.POINTER(fsr1_params), _STG, ctypes.c_void_p]),
+    "fsr1_upscale_plan": (ctypes.c_int, [_IMG, ctypes.c_int32, _IMG, ctypes.POINTER(fsr1_params), ctypes.c_int32]),
     "fsr1_last_error": (ctypes.c_char_p, []),
     "fsr1_version": (ctypes.c_int, []),
     "fsr1_device_count": (ctypes.c_int, []),

@@ -224,7 +224,7 @@ def easu_rcas_fused_band(src, dst_band, easu_con, rcas_con=None, sharpness=0.25,
 def upscale_band(src, dst_band, out_size, band, mid=None, sharpness=0.25, flags=0, stream=None, fused=False):
     """EASU + RCAS for output rows [band[0], band[1]) of an `out_size` = (width, height) upscale of `src`, written to `dst_band`
     (band[1] - band[0] rows): what one GPU does when a single frame is split into row bands.  `mid` (optional)
-    is a scratch tensor of at least band rows + 2; fused=True takes the single launch (no intermediary); returns dst_band."""
+    is a scratch tensor of at least band rows + 3; fused=True takes the single launch (no intermediary); returns dst_band."""
     import torch
     ow, oh = out_size
     y0, y1 = band
@@ -233,11 +233,16 @@ def upscale_band(src, dst_band, out_size, band, mid=None, sharpness=0.25, flags=
     if fused:
         return easu_rcas_fused_band(src, dst_band, con, sharpness=sharpness, origin_y=y0, rows_above=int(y0 > 0), rows_below=int(y1 < oh),
                                     flags=flags, stream=stream)
-    m0, m1 = max(y0 - 1, 0), min(y1 + 1, oh)  # EASU rows the band's RCAS taps read
+    # EASU rows the band's RCAS taps read: one either side — started on an even row, so that at exactly 2x every band (not
+    # only the first) runs the exact-2x kernel, whose quads need an even origin
+    m0, m1 = max(y0 - 1, 0) & ~1, min(y1 + 1, oh)
     if mid is None:
         mid = torch.empty(m1 - m0, ow, 4, dtype=dst_band.dtype, device=dst_band.device)
     mid = mid[:m1 - m0]
-    easu_band(src, mid, con, origin=(0, m0), flags=flags, stream=stream)
+    # FSR_Filter.cpp:107: EASU's Sample.x is 0 when RCAS follows — the HDR square, RCAS options and the store policy of the
+    # final image belong to the RCAS dispatch only (the fused launch squares once, and so must the two dispatches)
+    easu_flags = flags & (FLAG_MATH_EXACT | FLAG_MATH_PACKED_FP16 | FLAG_NO_FAST_PATHS)
+    easu_band(src, mid, con, origin=(0, m0), flags=easu_flags, stream=stream)
     rcas_band(mid[y0 - m0:y0 - m0 + (y1 - y0)], dst_band, sharpness=sharpness, rows_above=int(m0 < y0), rows_below=int(m1 > y1), flags=flags, stream=stream)
     return dst_band
 

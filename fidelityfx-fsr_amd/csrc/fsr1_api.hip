@@ -221,6 +221,31 @@ static bool color_format_pair_ok(int fin, int fout) {
   return fin == fout || (fin == FSR1_FORMAT_RGBA16F && (fout == FSR1_FORMAT_RGBA8_UNORM || fout == FSR1_FORMAT_R10G10B10A2_UNORM));
 }
 
+// fsr1_params.fused = 2 ("auto"), on round-2 measurements: at exactly 2x the quad form of the fused
+// launch (fsr1_fused_s2.hip) beats the two dispatches at every size; elsewhere the fused launch pays off only where a frame
+// is launch-bound (<= 3 Mpixel of output per launch).  The fused kernels' tile (one-pixel apron) needs more LDS than EASU's:
+// where it does not fit a CU's 160 KiB (about 1.9x minification and beyond) auto keeps the two dispatches the caller
+// supplied an intermediary for, instead of failing.
+static bool auto_takes_fused(const fsr1_image* in, bool have_intermediary, const fsr1_image* out, const uint32_t easu_con[16], uint32_t math,
+                             bool have_stages) {
+  if (!have_intermediary) return true;
+  const bool packed = (math & FSR1_FLAG_MATH_PACKED_FP16) != 0;
+  const bool con_2x = easu_con[0] == 0x3f000000u && easu_con[1] == 0x3f000000u && easu_con[2] == 0xbe800000u && easu_con[3] == 0xbe800000u;
+  const bool quad_form = con_2x && !(math & (FSR1_FLAG_MATH_PACKED_FP16 | FSR1_FLAG_NO_FAST_PATHS)) && !have_stages;
+  if (!quad_form) {
+    float sx, sy, bx, by;
+    memcpy(&sx, &easu_con[0], 4);
+    memcpy(&sy, &easu_con[1], 4);
+    memcpy(&bx, &easu_con[2], 4);
+    memcpy(&by, &easu_con[3], 4);
+    const int fp_w = footprint_extent(out->width, kTileW, 1, sx, bx), fp_h = footprint_extent(out->height, kFusedTileH, 1, sy, by);
+    if (fp_w < 0 || fp_h < 0) return false;
+    if ((packed ? fused_h_lds_bytes(fp_w, fp_h) : fused_lds_bytes(in->format, fp_w, fp_h)) > 160 * 1024) return false;
+  }
+  const long long out_pixels = (long long)out->width * (long long)out->height * (long long)out->frames;
+  return quad_form || out_pixels <= 3000000ll;
+}
+
 extern "C" {
 
 const char* fsr1_last_error(void) { return g_err; }
@@ -525,17 +550,8 @@ int fsr1_upscale_ex(const fsr1_image* in, const fsr1_image* intermediary, const 
   }
   FsrRcasCon(rcas_con, p->rcas_attenuation);  // :124
   const uint32_t rcas_flags = math | rcas_opts | out_policy | (p->hdr ? FSR1_FLAG_HDR_SQUARE : 0u);  // :125 Sample.x = hdr
-  bool fused = p->fused == 1;
-  if (p->fused == 2) {
-    // auto, on round-2 measurements: at exactly 2x the quad form of the fused launch (fsr1_fused_s2.hip) beats
-    // the two dispatches at every size; elsewhere the fused launch pays off only where a frame is launch-bound
-    const long long out_pixels = (long long)out->width * (long long)out->height * (long long)out->frames;
-    const bool quad_form = easu_con[0] == 0x3f000000u && easu_con[1] == 0x3f000000u && easu_con[2] == 0xbe800000u && easu_con[3] == 0xbe800000u &&
-                           !(math & (FSR1_FLAG_MATH_PACKED_FP16 | FSR1_FLAG_NO_FAST_PATHS)) && !stages;
-    fused = !intermediary || quad_form || out_pixels <= 3000000ll;
-  } else if (p->fused != 0 && p->fused != 1) {
-    return fail(FSR1_ERR_INVALID_ARGUMENT, "upscale: params.fused must be 0, 1 or 2 (auto)");
-  }
+  if (p->fused != 0 && p->fused != 1 && p->fused != 2) return fail(FSR1_ERR_INVALID_ARGUMENT, "upscale: params.fused must be 0, 1 or 2 (auto)");
+  const bool fused = p->fused == 1 || (p->fused == 2 && auto_takes_fused(in, intermediary != nullptr, out, easu_con, math, stages != nullptr));
   if (fused) return fsr1_easu_rcas_fused_dispatch_ex(in, out, easu_con, rcas_con, rcas_flags, stages, stream);
   if (!intermediary) return fail(FSR1_ERR_INVALID_ARGUMENT, "upscale: two-pass EASU+RCAS needs an intermediary image");
   // two dispatches: the prologue belongs to EASU's loads, the epilogue to RCAS's stores
@@ -555,6 +571,23 @@ int fsr1_upscale_ex(const fsr1_image* in, const fsr1_image* intermediary, const 
   if (rc) return rc;
   // :130 the UAV->SRV barrier is stream order here
   return fsr1_rcas_dispatch_ex(intermediary, out, rcas_con, rcas_flags, post_p, stream);  // :131
+}
+
+// Which pipeline fsr1_upscale[_ex] runs for these arguments (no launch): 0 = EASU + RCAS as two dispatches, 1 = the single
+// fused launch, 2 = EASU only (use_rcas == 0).
+int fsr1_upscale_plan(const fsr1_image* in, int32_t have_intermediary, const fsr1_image* out, const fsr1_params* p, int32_t have_stages) {
+  if (!in || !out || !p) return fail(FSR1_ERR_INVALID_ARGUMENT, "upscale_plan: null argument");
+  if (!(p->render_width >= 1.0f) || !(p->render_height >= 1.0f) || out->width <= 0 || out->height <= 0 || out->frames <= 0)
+    return fail(FSR1_ERR_INVALID_ARGUMENT, "upscale_plan: bad extents");
+  if (!p->use_rcas) return 2;
+  if (p->fused == 0) return 0;
+  if (p->fused == 1) return 1;
+  if (p->fused != 2) return fail(FSR1_ERR_INVALID_ARGUMENT, "upscale_plan: params.fused must be 0, 1 or 2 (auto)");
+  uint32_t easu_con[16];
+  FsrEasuCon(easu_con, easu_con + 4, easu_con + 8, easu_con + 12, p->render_width, p->render_height, p->render_width, p->render_height,
+             (float)out->width, (float)out->height);
+  const uint32_t math = p->flags & (FSR1_FLAG_MATH_EXACT | FSR1_FLAG_MATH_PACKED_FP16 | FSR1_FLAG_NO_FAST_PATHS);
+  return auto_takes_fused(in, have_intermediary != 0, out, easu_con, math, have_stages != 0) ? 1 : 0;
 }
 
 int fsr1_selftest(uint32_t* failures) {

@@ -6,6 +6,7 @@
 #include <stdint.h>
 
 #include <atomic>
+#include <mutex>
 
 #include "fsr1_device_base.hpp"
 #include "fsr1_device_color.hpp"
@@ -76,17 +77,21 @@ __device__ __forceinline__ int xcd_swizzle(int b, int n) {
 
 // Kernels that may need more than the default 48 KiB of dynamic LDS ask for it through hipFuncSetAttribute — once per
 // kernel, device and size: the attribute sticks, and re-issuing the call on every launch costs host time on the
-// launch path (round 1 did).  The cache is keyed by (device, function) and only ever grows.
+// launch path (round 1 did).  The cache is keyed by (device, function); the attribute only ever GROWS: raising it and
+// recording the new size happen under one mutex (two host threads launching the same kernel with different sizes could
+// otherwise leave the smaller size applied and the larger one recorded), the common case — already large enough — is one
+// atomic load.  Devices beyond the table (none exists: 64 per process) set the attribute on every launch, under the same mutex.
 inline hipError_t ensure_dynamic_lds(const void* fn, size_t lds) {
   if (lds <= 48 * 1024) return hipSuccess;
   struct Slot { std::atomic<const void*> fn{nullptr}; std::atomic<size_t> bytes{0}; };
-  constexpr int kDevices = 16, kSlots = 64;
+  constexpr int kDevices = 64, kSlots = 64;
   static Slot cache[kDevices][kSlots];
+  static std::mutex raise;
   int dev = 0;
   if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
-  Slot* row = cache[dev >= 0 && dev < kDevices ? dev : 0];
   Slot* slot = nullptr;
   if (dev >= 0 && dev < kDevices) {
+    Slot* row = cache[dev];
     for (int i = 0; i < kSlots && !slot; ++i) {
       const void* cur = row[i].fn.load(std::memory_order_acquire);
       if (cur == fn) slot = &row[i];
@@ -97,6 +102,8 @@ inline hipError_t ensure_dynamic_lds(const void* fn, size_t lds) {
     }
   }
   if (slot && slot->bytes.load(std::memory_order_acquire) >= lds) return hipSuccess;
+  std::lock_guard<std::mutex> lock(raise);
+  if (slot && slot->bytes.load(std::memory_order_relaxed) >= lds) return hipSuccess;  // another thread raised it meanwhile
   if (hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); e != hipSuccess) return e;
   if (slot) slot->bytes.store(lds, std::memory_order_release);
   return hipSuccess;

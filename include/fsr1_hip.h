@@ -87,7 +87,14 @@ enum {
   FSR1_FLAG_RCAS_PASSTHROUGH_ALPHA = 1u << 2,
   /* Arithmetic selection.  Default (neither bit): fp32 arithmetic with FMA contraction in the
    * continuous part of the filter — the FsrEasuF / FsrRcasF entry points ("F" parity class:
-   * within 1 binary16 ULP of the reference's CPU-evaluated F path).
+   * within 1 binary16 ULP of the reference's CPU-evaluated F path FOR INPUT IN THE RANGE THE
+   * REFERENCE DEFINES THE FILTERS ON, {0 to 1} ("RCAS solves for 'w' by seeing where the signal
+   * might clip out of the {0 to 1} input range", ffx_fsr1.h:618; linear HDR {0 to FP16_MAX} goes
+   * through FsrSrtmF into {0 to 1} first, :1035-1040).  Outside
+   * that range the class still holds for >= 99.9 % of the values, but where one 12-tap window mixes
+   * magnitudes 1e4 ... 1e10 apart the negative lobes cancel terms far larger than the result and
+   * about one value in 1e4 lands 2-8 ULP away (tests/test_gpu_special_values.py); EXACT has no such
+   * boundary: it is bit-identical for every input, NaN / Inf / signed zeros included).
    * EXACT: fp32 arithmetic in the reference's exact operation order, no contraction, IEEE
    * division — bit-identical (fp32) to the CPU-evaluated FsrEasuF / FsrRcasF.
    * PACKED_FP16: the FsrEasuH / FsrRcasH entry points — packed binary16 arithmetic
@@ -239,7 +246,9 @@ typedef struct fsr1_params {
                                           otherwise the two dispatches whenever the launch has more than 3 Mpixel of output
                                           (4K at 1.5x: 80.7 vs 88.8 us) and the fused launch below that, where a frame is
                                           launch-bound, for every arithmetic (FSR1_FLAG_MATH_PACKED_FP16 has a fused launch
-                                          too); with intermediary == NULL it is the fused launch */
+                                          too) — and only where the fused tile fits a CU's LDS (up to about 1.9x
+                                          minification; beyond that auto keeps the two dispatches); with intermediary == NULL
+                                          it is the fused launch */
   uint32_t flags;                      /* FSR1_FLAG_MATH_*, FSR1_FLAG_RCAS_DENOISE / _PASSTHROUGH_ALPHA, FSR1_FLAG_OUTPUT_* (of the pass that writes `out`) */
 } fsr1_params;
 
@@ -251,6 +260,13 @@ int fsr1_upscale(const fsr1_image* in, const fsr1_image* intermediary, const fsr
  * pass that writes `out` (RCAS, or EASU when use_rcas == 0), after the `hdr` square. */
 int fsr1_upscale_ex(const fsr1_image* in, const fsr1_image* intermediary, const fsr1_image* out,
                     const fsr1_params* params, const fsr1_color_stages* stages, void* stream);
+
+/* Which pipeline fsr1_upscale[_ex] would run for these arguments, without launching anything: 0 = EASU + RCAS as two
+ * dispatches, 1 = the single fused launch, 2 = EASU only (use_rcas == 0); a negative fsr1_status for bad arguments.
+ * have_intermediary / have_stages: whether the call would pass an intermediary image / colour stages.  Lets a host that
+ * uses fused = 2 ("auto") account bytes and report timings for the path actually taken (runner/fsr1_runner.c). */
+int fsr1_upscale_plan(const fsr1_image* in, int32_t have_intermediary, const fsr1_image* out, const fsr1_params* params,
+                      int32_t have_stages);
 
 /* ------------------------------------------------------------------------------------------------
  * Diagnostics

@@ -65,6 +65,8 @@ typedef struct {
   int status;
   char error[256];
   int ring;
+  int plan; /* pipeline actually run: 0 two dispatches, 1 fused launch, 2 EASU only (fsr1_upscale_plan) */
+  int comm_ranks; /* ncclCommCount of this rank's communicator */
   /* device resources, released by worker() after the collective */
   hipStream_t stream;
   hipEvent_t ev0, ev1;
@@ -148,13 +150,14 @@ static void shard(int total, int rank, int world, int* begin, int* end) {
   *end = *begin + q + (rank < r ? 1 : 0);
 }
 
-/* --bands: this GPU's band of every frame.  Band boundaries are even rows (the exact-2x kernel's quads). */
+/* --bands: this GPU's band of every frame.  Band boundaries are even rows, and the band's intermediary starts on an even row
+ * (two rows above the band instead of one): at exactly 2x every band then runs the exact-2x kernel, whose quads need an even origin. */
 static int worker_body_bands(worker_t* w) {
   const options_t* o = w->opt;
   hipStream_t stream = w->stream;
   int y0 = (int)((long long)o->out_h * w->rank / o->gpus) & ~1, y1 = w->rank + 1 == o->gpus ? o->out_h : ((int)((long long)o->out_h * (w->rank + 1) / o->gpus) & ~1);
   const int rows = y1 - y0;
-  const int m0 = y0 > 0 ? y0 - 1 : 0, m1 = y1 < o->out_h ? y1 + 1 : o->out_h;  /* EASU rows the band's RCAS taps read */
+  const int m0 = (y0 > 0 ? y0 - 1 : 0) & ~1, m1 = y1 < o->out_h ? y1 + 1 : o->out_h;  /* EASU rows the band's RCAS taps read (from an even row) */
   const size_t in_frame = (size_t)o->in_w * o->in_h * 8, pitch = (size_t)o->out_w * 8;
   const size_t band_set = in_frame + pitch * (size_t)(rows > 0 ? rows : 1);
   int ring = o->ring > 0 ? o->ring : (int)(((size_t)1024u * 1024u * 1024u + band_set - 1) / band_set);
@@ -273,6 +276,11 @@ static int worker_body(worker_t* w) {
   p.fused = o->pipeline == 1 ? 1 : (o->pipeline == 3 ? 2 : 0);
   p.flags = o->math;
 
+  {
+    fsr1_image pin = {NULL, o->in_w, o->in_h, FSR1_FORMAT_RGBA16F, nf > 0 ? nf : 1, 0, 0}, pout = {NULL, o->out_w, o->out_h, FSR1_FORMAT_RGBA16F, nf > 0 ? nf : 1, 0, 0};
+    w->plan = fsr1_upscale_plan(&pin, needs_mid, &pout, &p, o->stages != 0);
+    if (w->plan < 0) { snprintf(w->error, sizeof w->error, "fsr1_upscale_plan: %s", fsr1_last_error()); w->status = w->plan; return -1; }
+  }
   HIP_OK(w, hipEventCreate(&w->ev0));
   HIP_OK(w, hipEventCreate(&w->ev1));
   float ms = 0.f;
@@ -302,6 +310,7 @@ static int worker_body(worker_t* w) {
 /* the one collective: all-gather of 3 x uint64 per GPU over RCCL */
 static int worker_collective(worker_t* w) {
   const options_t* o = w->opt;
+  NCCL_OK(w, ncclCommCount(w->comm, &w->comm_ranks));
   NCCL_OK(w, ncclAllGather(w->d_send, w->d_recv, 3, ncclUint64, w->comm, w->stream));
   HIP_OK(w, hipStreamSynchronize(w->stream));
   if (w->rank == 0) HIP_OK(w, hipMemcpy(w->gathered, w->d_recv, sizeof w->counters * o->gpus, hipMemcpyDeviceToHost));
@@ -406,14 +415,21 @@ int main(int argc, char** argv) {
     }
     const double sec = (double)max_ns * 1e-9;
     const size_t in_b = (size_t)o.in_w * o.in_h * 8, out_b = (size_t)o.out_w * o.out_h * 8;
-    const double bytes = (double)frames * (double)(o.pipeline == 0 ? in_b + 3 * out_b : in_b + out_b);
+    /* the pipeline that ran: --bands runs what --pipeline says; otherwise what fsr1_upscale_plan reported for `auto` */
+    const int ran = o.bands ? (o.pipeline == 1 ? 1 : 0) : ws[0].plan;
+    const double bytes = (double)frames * (double)(ran == 0 ? in_b + 3 * out_b : in_b + out_b);
     printf("{\"metric\": \"upscaled megapixels/sec\", \"value\": %.1f, \"unit\": \"Mpix/s\", \"n_gpus\": %d, \"frames\": %llu, "
-           "\"steps\": %d, \"seconds\": %.6f, \"in\": \"%dx%d\", \"out\": \"%dx%d\", \"pipeline\": \"%s\", \"math\": \"%s\", \"color_stages\": %u, "
-           "\"algorithmic_GBps\": %.1f, \"hbm_peak_frac\": %.4f, \"rccl_ranks\": %d, \"ring\": %d, \"bands\": %d, \"per_gpu_ms\": [",
-           (double)pixels / sec / 1e6, o.gpus, (unsigned long long)frames, o.steps, sec, o.in_w, o.in_h, o.out_w, o.out_h,
-           o.pipeline == 0 ? "two-pass" : (o.pipeline == 1 ? "fused" : (o.pipeline == 2 ? "easu" : "auto")), o.math == FSR1_FLAG_MATH_EXACT ? "exact" : (o.math ? "h" : "f"), o.stages, bytes / sec / 1e9,
-           bytes / sec / 1e9 / (8000.0 * o.gpus), o.gpus, ws[0].ring, o.bands);
+           "\"steps\": %d, \"warmup\": %d, \"ms_per_step\": %.5f, \"seconds\": %.6f, \"higher_is_better\": true, \"scaling\": \"%s\", "
+           "\"in\": \"%dx%d\", \"out\": \"%dx%d\", \"pipeline\": \"%s\", \"pipeline_run\": \"%s\", \"math\": \"%s\", \"color_stages\": %u, "
+           "\"algorithmic_GBps\": %.1f, \"hbm_peak_frac\": %.4f, \"rccl_ranks\": %d, \"world_size_seen\": %d, \"ring\": %d, \"intermediary\": \"%s\", \"bands\": %d, \"per_gpu_ms\": [",
+           (double)pixels / sec / 1e6, o.gpus, (unsigned long long)frames, o.steps, o.warmup, sec * 1e3 / o.steps, sec, o.bands ? "strong" : "weak",
+           o.in_w, o.in_h, o.out_w, o.out_h,
+           o.pipeline == 0 ? "two-pass" : (o.pipeline == 1 ? "fused" : (o.pipeline == 2 ? "easu" : "auto")),
+           ran == 0 ? "two-pass" : (ran == 1 ? "fused" : "easu"), o.math == FSR1_FLAG_MATH_EXACT ? "exact" : (o.math ? "h" : "f"), o.stages, bytes / sec / 1e9,
+           bytes / sec / 1e9 / (8000.0 * o.gpus), o.gpus, ws[0].comm_ranks, ws[0].ring, ran == 0 ? "reused" : "none", o.bands);
     for (int i = 0; i < o.gpus; ++i) printf("%s%.3f", i ? ", " : "", (double)gathered[3 * i + 2] * 1e-6);
+    printf("], \"per_rank_seconds\": [");
+    for (int i = 0; i < o.gpus; ++i) printf("%s%.6f", i ? ", " : "", (double)gathered[3 * i + 2] * 1e-9);
     printf("]}\n");
   }
   pthread_barrier_destroy(&g_before_collective);

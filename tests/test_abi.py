@@ -131,6 +131,35 @@ def test_upscale_parameter_validation(fsr):
     assert b"intermediary" in lib.fsr1_last_error()
 
 
+def test_upscale_plan_auto_rule(fsr):
+    """fsr1_upscale_plan: the pipeline `fused = 2` (auto) takes, decided on the host without a launch — the fused quad form at
+    exactly 2x, the fused launch for launch-bound frames, two dispatches for large frames at other ratios, and two
+    dispatches (not an error) where the fused tile would not fit a CU's LDS but an intermediary was supplied."""
+    lib = fsr.load()
+    P = fsr._lib.fsr1_params
+
+    def plan(iw, ih, ow, oh, fused=2, have_mid=1, flags=0, use_rcas=1, frames=1, stages=0):
+        a = fsr.fsr1_image(0x1000, iw, ih, 0, frames, 0, 0)
+        b = fsr.fsr1_image(0x10000000, ow, oh, 0, frames, 0, 0)
+        return lib.fsr1_upscale_plan(ctypes.byref(a), have_mid, ctypes.byref(b), ctypes.byref(P(float(iw), float(ih), use_rcas, 0.25, 0, fused, flags)), stages)
+
+    assert plan(1920, 1080, 3840, 2160) == 1                      # exactly 2x: the quad-form single launch
+    assert plan(1920, 1080, 3840, 2160, flags=1 << 8) == 0        # NO_FAST_PATHS: generic kernels, 8.3 Mpixel -> two dispatches
+    assert plan(1920, 1080, 3840, 2160, flags=1 << 5) == 0        # packed fp16 has no quad-form fused kernel
+    assert plan(1920, 1080, 3840, 2160, stages=1) == 0            # colour stages neither
+    assert plan(2560, 1440, 3840, 2160) == 0                      # 1.5x at 4K: two dispatches
+    assert plan(1280, 720, 1920, 1080) == 1                       # 1.5x at 1080p: launch-bound, fused
+    assert plan(1280, 720, 1920, 1080, frames=4) == 0             # ... but not four of them in one launch
+    assert plan(2560, 1440, 3840, 2160, have_mid=0) == 1          # no intermediary: only the fused launch can run
+    assert plan(2560, 1440, 3840, 2160, fused=0) == 0 and plan(2560, 1440, 3840, 2160, fused=1) == 1
+    assert plan(2560, 1440, 3840, 2160, use_rcas=0) == 2          # EASU only
+    # about 2x minification: EASU's tile fits the LDS, the fused tile (one-pixel apron, intermediate tile) does not
+    assert plan(1920, 1080, 960, 540) == 0
+    assert plan(1920, 1080, 960, 540, flags=1 << 5) == 0
+    assert plan(1920, 1080, 3840, 2160, fused=3) == -1 and b"fused" in lib.fsr1_last_error()
+    assert lib.fsr1_upscale_plan(None, 1, None, None, 0) == -1
+
+
 @pytest.mark.gpu
 def test_roctx_ranges_can_be_switched_on():
     """FSR1_ROCTX=1 wraps every dispatch in a roctx range (resolved with dlopen; SURVEY.md section 5 tracing): the smoke

@@ -70,6 +70,29 @@ def test_fused_bands_reassemble_into_the_full_frame(fsr, shape, n_bands):
     assert torch.equal(two.view(torch.int16), full.view(torch.int16))  # two-dispatch bands == fused full frame
 
 
+@pytest.mark.parametrize("shape", [(640, 360, 1280, 720), (97, 61, 131, 83)], ids=lambda s: "%dx%d_to_%dx%d" % s)
+def test_hdr_bands_square_once(fsr, shape):
+    """FSR1_FLAG_HDR_SQUARE (`c *= c`, FSR_Pass.hlsl:78-79) with RCAS on belongs to the RCAS dispatch only (FSR_Filter.cpp:107:
+    EASU's Sample.x is 0 when RCAS follows): the two-dispatch bands, the fused bands and the full frame agree bit for bit,
+    and they are what fsr1_upscale(hdr = 1) writes."""
+    iw, ih, ow, oh = shape
+    src = dev(frames.synthetic_frame(iw, ih, k=5, dtype=np.float16))
+    for math in (0, fsr.FLAG_MATH_EXACT):
+        flags = math | fsr.FLAG_HDR_SQUARE | fsr.FLAG_RCAS_DENOISE
+        mid = torch.zeros(oh, ow, 4, dtype=torch.float16, device="cuda")
+        full = torch.zeros_like(mid)
+        fsr.easu(src, mid, flags=math)          # Sample.x = 0
+        fsr.rcas(mid, full, sharpness=0.25, flags=flags)  # Sample.x = hdr
+        fused_full = torch.zeros_like(full)
+        fsr.easu_rcas_fused(src, fused_full, sharpness=0.25, flags=flags)
+        assert torch.equal(fused_full.view(torch.int16), full.view(torch.int16))
+        for fused in (False, True):
+            out = torch.full_like(full, -1.0)
+            for (y0, y1) in splits(oh, 3, False):
+                fsr.upscale_band(src, out[y0:y1], (ow, oh), (y0, y1), sharpness=0.25, flags=flags, fused=fused)
+            assert torch.equal(out.view(torch.int16), full.view(torch.int16)), "hdr bands (fused=%s, math=%d) differ from the full frame" % (fused, math)
+
+
 def test_fused_band_batch_and_rgba8(fsr):
     """Several frames per launch share the band geometry; UNORM storage goes through the same apron logic."""
     iw, ih, ow, oh = 96, 54, 192, 108

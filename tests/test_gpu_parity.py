@@ -440,7 +440,10 @@ def test_upscale_auto_pipeline(fsr, port):
     include/fsr1_hip.h); the image is the same either way (fused == two-pass bit for bit), so only the choice itself needs
     checking: the intermediary is written iff two-pass ran."""
     for (iw, ih, ow, oh), expect_two_pass in (((160, 90, 320, 180), False), ((160, 90, 240, 135), False), ((1280, 720, 2560, 1440), False),
-                                              ((1707, 960, 2560, 1440), True)):
+                                              ((1707, 960, 2560, 1440), True),
+                                              # 2x minification: EASU's tile fits a CU's LDS, the fused tile does not — auto keeps
+                                              # the two dispatches it was given an intermediary for instead of failing
+                                              ((640, 360, 320, 180), True)):
         src = dev(frames.synthetic_frame(iw, ih, k=2, dtype=np.float16))
         dst = torch.zeros(oh, ow, 4, dtype=torch.float16, device="cuda")
         filt = fsr.FSR_Filter()

@@ -34,6 +34,12 @@ def test_runner_on_gpu(runner, pipeline):
     d = json.loads(out.stdout.strip().splitlines()[-1])
     assert d["n_gpus"] == 1 and d["frames"] == 60 and d["pipeline"] == pipeline
     assert d["value"] > 1000.0  # Mpix/s; the CPU reference does ~25 on 128 cores
+    # the same fields as bench.py's line; `auto` reports the pipeline it took (exactly 2x: the fused quad form) and the
+    # algorithmic byte count follows that path, not the request
+    assert d["steps"] == 20 and d["warmup"] == 3 and d["scaling"] == "weak" and d["higher_is_better"] is True
+    assert d["world_size_seen"] == 1 and len(d["per_rank_seconds"]) == 1 and abs(d["ms_per_step"] - d["seconds"] * 1e3 / 20) < 1e-3
+    assert d["pipeline_run"] == {"two-pass": "two-pass", "fused": "fused", "easu": "easu", "auto": "fused"}[pipeline]
+    assert d["intermediary"] == ("reused" if pipeline == "two-pass" else "none")
 
 
 @pytest.mark.gpu
@@ -72,7 +78,7 @@ def test_runner_two_gpus_over_rccl(runner, fsr):
                           "--warmup", "3"], capture_output=True, text=True, timeout=1200)
     assert out.returncode == 0, out.stdout + out.stderr
     d = json.loads(out.stdout.strip().splitlines()[-1])
-    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["frames"] == 100 and len(d["per_gpu_ms"]) == 2
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["world_size_seen"] == 2 and d["frames"] == 100 and len(d["per_gpu_ms"]) == 2
     assert all(ms > 0 for ms in d["per_gpu_ms"])
 
 

@@ -51,6 +51,61 @@ def test_counter_reduction_gloo_world2(tmp_path):
     assert out.stdout.count("ok") == 2
 
 
+def _bench_line(cmd, env=None, timeout=600):
+    import json
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "exactly ONE JSON line expected, got %d:\n%s" % (len(lines), out.stdout[-2000:])
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("n", [1, 2])
+@pytest.mark.parametrize("style", ["bare", "torchrun"])
+def test_bench_launch_styles_stub(n, style):
+    """Both ways the driver may start `bench.py --gpus N` — a bare `python bench.py --gpus N` (bench.py starts the ranks
+    itself) and `python -m torch.distributed.run ... bench.py --gpus N` — give one JSON line with the contract's fields,
+    the world size the process group saw and every rank's seconds.  --stub: rendezvous, barriers and the counters-only
+    collectives over gloo with 1 ms of sleep per step instead of GPU work, so the plumbing runs on the CPU-only builder."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "FSR1_BENCH_SELF_LAUNCHED")}
+    tail = [os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "6", "--warmup", "2", "--stub"]
+    if style == "bare":
+        cmd = [sys.executable] + tail
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+               "--master-port", str(29640 + n)] + tail
+    line = _bench_line(cmd, env)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert key in line, key
+    assert line["n_gpus"] == n and line["steps"] == 6 and line["warmup"] == 2 and line["scaling"] == "weak" and line["data"] == "stub"
+    assert line["config"]["world_size_seen"] == n and len(line["per_rank_seconds"]) == n
+    assert line["config"]["frames_total"] == 6 * n  # weak scaling: every rank did its own K steps
+    assert abs(line["ms_per_step"] - max(line["per_rank_seconds"]) * 1e3 / 6) < 1e-3  # MAX over ranks
+    if n > 1:
+        assert ("self-launched" in line["config"]["launch"]) == (style == "bare")
+
+
+def test_bench_world_size_mismatch_is_an_error():
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--stub"], capture_output=True, text=True, timeout=120, cwd=ROOT, env=env)
+    assert out.returncode != 0 and "does not match" in out.stderr
+
+
+@pytest.mark.gpu
+def test_bench_self_launch_two_ranks_on_the_visible_gpus():
+    """The real bench step under the N-rank launch on whatever this box has: two ranks, each driving the HIP path, counters over
+    RCCL when two GPUs are visible, over gloo with the ranks sharing the one GPU otherwise (RCCL refuses two ranks on a device)."""
+    torch = pytest.importorskip("torch")
+    two = torch.cuda.device_count() >= 2
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "30", "--warmup", "5", "--no-cpu-baseline", "--workload", "540p_to_1080p"]
+    if not two:
+        cmd += ["--backend", "gloo", "--oversubscribe"]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "FSR1_BENCH_SELF_LAUNCHED")}
+    line = _bench_line(cmd, env, timeout=900)
+    assert line["n_gpus"] == 2 and line["config"]["world_size_seen"] == 2 and len(line["per_rank_seconds"]) == 2
+    assert line["config"]["oversubscribed"] == (not two) and line["value"] > 0 and "roofline" in line
+
+
 @pytest.mark.gpu
 def test_bench_two_gpus_over_rccl():
     """bench.py --gpus 2 launched the way the driver launches it (one process per GPU, RCCL): skipped on a single-GPU box."""
