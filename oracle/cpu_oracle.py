@@ -67,6 +67,11 @@ class _Oracle:
             fn = g(prefix + n)
             fn.argtypes = [_FP, _I, _I, _FP, _U32P, _I, _I, _I]
             fn.restype = None
+        self.has_hx2 = hasattr(self.lib, prefix + "rcas_hx2")  # the reference build only: FsrRcasHx2 compiled from ffx_fsr1.h:888-984
+        if self.has_hx2:
+            fn = g(prefix + "rcas_hx2")
+            fn.argtypes = [_FP, _I, _I, _FP, _U32P, _I, _I, _I]
+            fn.restype = None
         for n in ("color_f", "color_h"):
             fn = g(prefix + n)
             fn.argtypes = [_FP, _I, _I, _FP, _I, _F, _F, ctypes.c_uint32, _FP, _I, _I, _I, _I, _I, _I, _I]
@@ -128,6 +133,12 @@ class _Oracle:
 
     def rcas_h(self, img, con4, flags=0, rows=None):
         return self._rcas("rcas_h", img, con4, flags, rows)
+
+    def rcas_hx2(self, img, con4, flags=0, rows=None):
+        """The reference's packed two-pixel form FsrRcasHx2 + FsrRcasDepackHx2 (ffx_fsr1.h:880-984), reference build only."""
+        if not self.has_hx2:
+            raise RuntimeError("rcas_hx2 exists in the reference build (oracle/_ref) only")
+        return self._rcas("rcas_hx2", img, con4, flags, rows)
 
 
     # ---- colour stages (LFGA / SRTM / TEPD) -------------------------------------------------

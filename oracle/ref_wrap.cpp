@@ -52,6 +52,7 @@ static inline vec4 load(int x, int y) {
 #define FSR_EASU_H 1
 #define FSR_RCAS_F 1
 #define FSR_RCAS_H 1
+#define FSR_RCAS_HX2 1 /* the packed two-pixel form (ffx_fsr1.h:874-984), compiled as well: tests pin FsrRcasHx2 to FsrRcasH with it */
 
 #define REF_CALLBACKS                                                                                   \
   vec4 FsrEasuRF(vec2 p) { return gather(p, 0); }                                                       \
@@ -63,7 +64,9 @@ static inline vec4 load(int x, int y) {
   vec4 FsrRcasLoadF(ivec2 p) { return load(p.x, p.y); }                                                 \
   void FsrRcasInputF(float& r, float& g, float& b) {}                                                   \
   f16vec4 FsrRcasLoadH(i16vec2 p) { return f16vec4(load(p.x, p.y)); }                                   \
-  void FsrRcasInputH(float16_t& r, float16_t& g, float16_t& b) {}
+  void FsrRcasInputH(float16_t& r, float16_t& g, float16_t& b) {}                                       \
+  f16vec4 FsrRcasLoadHx2(i16vec2 p) { return f16vec4(load(p.x, p.y)); }                                 \
+  void FsrRcasInputHx2(f16vec2& r, f16vec2& g, f16vec2& b) {}
 
 // Four builds of the same header: the RCAS feature macros are compile-time (ffx_fsr1.h:647-651).
 namespace plain {
@@ -177,6 +180,34 @@ void ref_rcas_h(const float* in, int W, int H, float* out, const uint32_t* con, 
       if (flags & REF_HDR_SQUARE) c *= c;
       float* o = out + ((size_t)y * W + x) * 4;
       o[0] = c.x.v; o[1] = c.y.v; o[2] = c.z.v; o[3] = a.v;
+    }
+  }
+}
+
+// The packed form FsrRcasHx2 (ffx_fsr1.h:888-984): one call sharpens the pixels ip and ip + (8, 0) — "2 8x8 tiles in a 16x8
+// region" — in the two halves of every operand; FsrRcasDepackHx2 (:880-886) turns the result back into two pixels.  The image is
+// walked in 16-pixel-wide column blocks, the call at column x of a block's left half producing x and x + 8.
+void ref_rcas_hx2(const float* in, int W, int H, float* out, const uint32_t* con, int flags, int y0, int y1) {
+#pragma omp parallel for schedule(dynamic, 4)
+  for (int y = y0; y < y1; ++y) {
+    g_src = Image{in, W, H};
+    for (int bx = 0; bx < W; bx += 16) {
+      for (int x = bx; x < bx + 8 && x < W; ++x) {
+        f16vec2 r, g, b, a(float16_t(1.0), float16_t(1.0));
+        uvec2 ip((uint)x, (uint)y);
+        switch (flags & 3) {
+          case 0: plain::FsrRcasHx2(r, g, b, ip, con4(con)); break;
+          case REF_RCAS_DENOISE: denoise::FsrRcasHx2(r, g, b, ip, con4(con)); break;
+          case REF_RCAS_ALPHA: alpha::FsrRcasHx2(r, g, b, a, ip, con4(con)); break;
+          default: alpha_denoise::FsrRcasHx2(r, g, b, a, ip, con4(con)); break;
+        }
+        if (flags & REF_HDR_SQUARE) { r *= r; g *= g; b *= b; }
+        f16vec4 p0, p1;
+        plain::FsrRcasDepackHx2(p0, p1, r, g, b);
+        float* o = out + ((size_t)y * W + x) * 4;
+        o[0] = p0.x.v; o[1] = p0.y.v; o[2] = p0.z.v; o[3] = a.x.v;
+        if (x + 8 < W) { o += 32; o[0] = p1.x.v; o[1] = p1.y.v; o[2] = p1.z.v; o[3] = a.y.v; }
+      }
     }
   }
 }

@@ -178,6 +178,9 @@ def test_whole_frame_packed_fp16(fsr, checker, name):
     got_mid = host(mid)
     assert_exact16(got_mid, checker.easu_h(img.astype(np.float32), ow, oh, con), name + " easu H")
     assert_exact16(host(out), checker.rcas_h(got_mid.astype(np.float32), rc), name + " rcas H")
+    if getattr(checker, "has_hx2", False) and name == "1080p_to_4k":
+        # the packed two-pixel entry point compiled from the reference (FsrRcasHx2 + FsrRcasDepackHx2, ffx_fsr1.h:880-984): a whole 4K frame
+        assert_exact16(host(out), checker.rcas_hx2(got_mid.astype(np.float32), rc), name + " rcas Hx2")
     fus = torch.zeros_like(mid)
     fsr.easu_rcas_fused(src, fus, easu_con=con, rcas_con=rc, flags=fsr.FLAG_MATH_PACKED_FP16)
     assert torch.equal(out.view(torch.int16), fus.view(torch.int16)), name + ": fused H launch differs from the two H dispatches"
@@ -208,6 +211,39 @@ def test_whole_frame_rgba8(fsr, checker, name):
         want[..., 3] = 255
         check_codes(host(dst), want, exact, "%s rgba8 rcas exact=%s" % (name, exact))
         assert torch.equal(dst, fus), "%s rgba8: fused differs from two-pass" % name
+
+
+def test_whole_frame_rgb10a2(fsr, checker):
+    """R10G10B10A2 UNORM — the format the sample's HDR path renders into and presents (sample/src/DX12/FSR_Filter.cpp:72-73,
+    SampleRenderer.cpp:193) — at full size, 1080p -> 4K: EXACT reproduces every 10-bit (and 2-bit alpha) code of the
+    reference run on the decoded image, the default arithmetic is within one code with >= 99.5 % equal; the fused launch
+    equals the two dispatches word for word."""
+    from test_gpu_unorm import pack10, unpack10, check_codes
+    iw, ih, ow, oh = SHAPES["1080p_to_4k"]
+    img = frames.synthetic_frame(iw, ih, k=4, dtype=np.float32)
+    img[..., 3] = (np.arange(iw)[None, :] % 4) / 3.0
+    words = pack10(img)
+    con = checker.FsrEasuCon(iw, ih, iw, ih, ow, oh)
+    rc = checker.FsrRcasCon(0.25)
+    src = torch.from_numpy(words.view(np.int32)).cuda()
+    fields = ((0, 0x3FF, "R"), (10, 0x3FF, "G"), (20, 0x3FF, "B"), (30, 0x3, "A"))
+    want_mid = pack10(checker.easu_f(unpack10(words), ow, oh, con))  # alpha = 1 out of EASU
+    for exact in (True, False):
+        fl = fsr.FLAG_MATH_EXACT if exact else 0
+        mid = torch.zeros(oh, ow, dtype=torch.int32, device="cuda")
+        dst = torch.zeros_like(mid)
+        fus = torch.zeros_like(mid)
+        fsr.easu(src, mid, con=con, flags=fl)
+        fsr.rcas(mid, dst, con=rc, flags=fl | fsr.FLAG_RCAS_PASSTHROUGH_ALPHA)
+        fsr.easu_rcas_fused(src, fus, easu_con=con, rcas_con=rc, flags=fl | fsr.FLAG_RCAS_PASSTHROUGH_ALPHA)
+        got_mid = host(mid).view(np.uint32)
+        for sh, n, ch in fields:
+            check_codes((got_mid >> sh) & n, (want_mid >> sh) & n, exact, "rgb10a2 easu %s exact=%s" % (ch, exact))
+        want = pack10(checker.rcas_f(unpack10(got_mid), rc, 2))  # 2 = pass alpha through; judged on the GPU's own intermediary
+        got = host(dst).view(np.uint32)
+        for sh, n, ch in fields:
+            check_codes((got >> sh) & n, (want >> sh) & n, exact, "rgb10a2 rcas %s exact=%s" % (ch, exact))
+        assert torch.equal(dst, fus), "rgb10a2: fused differs from two-pass"
 
 
 def _batch(fsr, checker, name, n, pipelines):

@@ -72,6 +72,22 @@ def test_rcas_h_golden(fsr, name):
         assert_bits16(host(out), g["rcas_h_%d" % fl], "rcas H %s flags=%d" % (name, fl))
 
 
+@pytest.mark.parametrize("name", PIXEL_CASES)
+def test_rcas_h_kernel_vs_reference_hx2(fsr, name):
+    """The H kernel against the reference's packed entry point itself — FsrRcasHx2 + FsrRcasDepackHx2 compiled from
+    ffx_fsr1.h:880-984 (oracle/_ref) — on the golden intermediaries, every option."""
+    import cpu_oracle
+    if not cpu_oracle.have_ref() or not cpu_oracle.ref().has_hx2:
+        pytest.skip("oracle/_ref with FsrRcasHx2 not available")
+    ref = cpu_oracle.ref()
+    g = load_golden(name)
+    mid = g["mid"]
+    for fl in (0, 1, 2, 3):
+        out = torch.zeros(mid.shape, dtype=torch.float16, device="cuda")
+        fsr.rcas(dev(mid), out, con=g["rcas_con"], flags=fsr.FLAG_MATH_PACKED_FP16 | rcas_flags(fsr, fl))
+        assert_bits16(host(out), ref.rcas_hx2(mid.astype(np.float32), g["rcas_con"], fl), "rcas H vs FsrRcasHx2 %s flags=%d" % (name, fl))
+
+
 SHAPES = [(480, 270, 960, 540), (369, 208, 480, 270), (564, 317, 960, 540), (640, 360, 960, 540), (97, 61, 131, 83),
           (5, 3, 17, 9), (64, 16, 64, 16), (1, 1, 3, 2)]
 

@@ -61,6 +61,33 @@ def test_port_matches_reference_build(port, ref, shape):
             assert same_bits(port.rcas_h(mid, rc, fl), ref.rcas_h(mid, rc, fl)), (stops, fl)
 
 
+@pytest.mark.parametrize("shape", [(131, 83), (64, 16), (23, 9), (16, 5), (9, 4), (8, 3), (1, 1)], ids=lambda s: "%dx%d" % s)
+def test_reference_hx2_is_h_lane_by_lane(port, ref, shape):
+    """FsrRcasHx2 (ffx_fsr1.h:888-984, two pixels eight columns apart in the halves of every operand) compiled from the
+    reference and compared with FsrRcasH (:782-866) of the same build, pixel for pixel: the packed form runs the same
+    binary16 operations per lane.  That is what lets one H kernel (csrc/fsr1_rcas_h.hip) stand for both entry points —
+    pinned here by the compiled token stream, not by reading.  Widths that are not multiples of 16 included."""
+    w, h = shape
+    img = frames.synthetic_frame(w, h, k=7, dtype=np.float16).astype(np.float32)
+    img[..., 3] = (np.arange(w, dtype=np.float32)[None, :] / max(w, 1)).astype(np.float16)  # alpha worth passing through
+    hostile = frames.adversarial_frame(w, h, k=1).astype(np.float32) if hasattr(frames, "adversarial_frame") else img
+    for src in (img, hostile):
+        for stops in (0.0, 0.25, 2.0):
+            rc = ref.FsrRcasCon(stops)
+            for fl in range(8):
+                a, b = ref.rcas_hx2(src, rc, fl), ref.rcas_h(src, rc, fl)
+                assert same_bits(a, b), (shape, stops, fl)
+                assert same_bits(port.rcas_h(src, rc, fl), a), (shape, stops, fl)  # and the restatement equals both
+
+
+@pytest.mark.parametrize("name", PIXEL_CASES)
+def test_reference_hx2_matches_golden(ref, name):
+    g = load_golden(name)
+    mid = g["mid"].astype(np.float32)
+    for fl in range(4):
+        assert same_bits(ref.rcas_hx2(mid, g["rcas_con"], fl), g["rcas_h_%d" % fl].astype(np.float32)), fl
+
+
 def test_port_dynamic_resolution_viewport(port, ref):
     """Viewport smaller than the resource + offset (FsrEasuConOffset): taps clamp at the resource edge."""
     img = frames.synthetic_frame(64, 48, k=2, dtype=np.float32)
