@@ -29,6 +29,7 @@ def child(args):
     flags = {"f": 0, "exact": fsr.FLAG_MATH_EXACT, "h": fsr.FLAG_MATH_PACKED_FP16}[args.math]
     if args.no_fast_paths:
         flags |= fsr.FLAG_NO_FAST_PATHS
+    flags |= int(os.environ.get("FSR1_AB_FLAGS", "0"), 0)  # `lib@flags` in --libs: extra dispatch flag bits of this variant
     timer = fsr.Timer()
     for wl in args.workloads.split(","):
         in_w, in_h, out_w, out_h, frames = bench.WORKLOADS[wl]
@@ -65,7 +66,8 @@ def child(args):
             return timer.elapsed_ms() / n
 
         n = max(10, int(args.launches / max(1, frames)))
-        row = {"lib": os.path.basename(os.environ.get("FSR1_HIP_LIB", "default")), "workload": wl, "math": args.math}
+        row = {"lib": os.path.basename(os.environ.get("FSR1_HIP_LIB", "default")) + ("@" + os.environ["FSR1_AB_FLAGS"] if os.environ.get("FSR1_AB_FLAGS") else ""),
+               "workload": wl, "math": args.math}
         for name, fn in (("easu", easu), ("rcas", rcas), ("rcas_cold", rcas_cold), ("pair", pair), ("fused", fused)):
             if name in args.kernels.split(","):
                 row[name + "_us"] = round(ms(fn, n) * 1e3, 2)
@@ -88,10 +90,13 @@ def main():
     args = ap.parse_args()
     if args.child:
         return child(args)
-    libs = [l for l in args.libs.split(",") if l] or [""]
+    libs = [l for l in args.libs.split(",") if l] or [""]  # "@0x800" alone = the tree's library with those flag bits
     for rep in range(args.reps):
         for lib in libs:
             env = dict(os.environ)
+            env.pop("FSR1_AB_FLAGS", None)
+            if "@" in lib:  # `path@flags`: the library (empty = the tree's) with extra dispatch flag bits, e.g. @0x800 = FSR1_FLAG_EASU_MATRIX_PIPE
+                lib, env["FSR1_AB_FLAGS"] = lib.split("@", 1)
             if lib:
                 env["FSR1_HIP_LIB"] = os.path.join(ROOT, lib)
             cmd = [sys.executable, os.path.abspath(__file__), "--child", "--workloads", args.workloads, "--kernels", args.kernels,
