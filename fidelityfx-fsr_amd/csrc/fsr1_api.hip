@@ -13,7 +13,6 @@
 
 namespace fsr1 {
 hipError_t easu_launch(const EasuArgs& a, int fmt, bool exact, bool s2, hipStream_t stream);
-hipError_t easu_mfma_launch(const EasuArgs& a, int fmt, hipStream_t stream);
 size_t easu_lds_bytes(int fmt, int fp_w, int fp_h);
 hipError_t rcas_launch(const RcasArgs& a, int fmt, bool exact, hipStream_t stream);
 void rcas_geometry(int width, int height, int frames, int* tiles_x, int* tiles_y, int* rows);
@@ -165,14 +164,7 @@ static int check_grid(const char* who, int tiles_x, int tiles_y, int frames) {
 
 static const uint32_t kKnownFlags = FSR1_FLAG_HDR_SQUARE | FSR1_FLAG_RCAS_DENOISE | FSR1_FLAG_RCAS_PASSTHROUGH_ALPHA |
                                     FSR1_FLAG_MATH_EXACT | FSR1_FLAG_MATH_PACKED_FP16 | FSR1_FLAG_NO_FAST_PATHS |
-                                    FSR1_FLAG_OUTPUT_STREAMING | FSR1_FLAG_OUTPUT_CACHED | FSR1_FLAG_EASU_MATRIX_PIPE |
-                                    FSR1_FLAG_EASU_NO_MATRIX_PIPE;
-
-// Whether the exact-2x default-arithmetic EASU takes the matrix-pipe kernel when the caller states no preference
-// (FSR1_FLAG_EASU_MATRIX_PIPE / _NO_MATRIX_PIPE).  Decided on measurements: DESIGN.md section 3.1.
-#ifndef FSR1_EASU_MFMA_DEFAULT
-#define FSR1_EASU_MFMA_DEFAULT 0
-#endif
+                                    FSR1_FLAG_OUTPUT_STREAMING | FSR1_FLAG_OUTPUT_CACHED;
 
 static int check_flags(uint32_t flags) {
   if (flags & ~kKnownFlags) return fail(FSR1_ERR_INVALID_ARGUMENT, "unknown flag bits 0x%x", flags & ~kKnownFlags);
@@ -180,8 +172,6 @@ static int check_flags(uint32_t flags) {
     return fail(FSR1_ERR_INVALID_ARGUMENT, "FSR1_FLAG_MATH_EXACT and FSR1_FLAG_MATH_PACKED_FP16 are exclusive");
   if ((flags & FSR1_FLAG_OUTPUT_STREAMING) && (flags & FSR1_FLAG_OUTPUT_CACHED))
     return fail(FSR1_ERR_INVALID_ARGUMENT, "FSR1_FLAG_OUTPUT_STREAMING and FSR1_FLAG_OUTPUT_CACHED are exclusive");
-  if ((flags & FSR1_FLAG_EASU_MATRIX_PIPE) && (flags & FSR1_FLAG_EASU_NO_MATRIX_PIPE))
-    return fail(FSR1_ERR_INVALID_ARGUMENT, "FSR1_FLAG_EASU_MATRIX_PIPE and FSR1_FLAG_EASU_NO_MATRIX_PIPE are exclusive");
   return FSR1_OK;
 }
 
@@ -344,9 +334,6 @@ static int easu_dispatch_impl(const fsr1_image* in, const fsr1_image* out, const
     e = easu_h_launch(a, s2, static_cast<hipStream_t>(stream));
   } else if (a.color.stages) {
     e = easu_color_launch(a, in->format, out->format, (flags & FSR1_FLAG_MATH_EXACT) != 0, static_cast<hipStream_t>(stream));
-  } else if (s2 && !(flags & FSR1_FLAG_MATH_EXACT) && kTileH == 16 &&
-             ((flags & FSR1_FLAG_EASU_MATRIX_PIPE) || (FSR1_EASU_MFMA_DEFAULT && !(flags & FSR1_FLAG_EASU_NO_MATRIX_PIPE)))) {
-    e = easu_mfma_launch(a, in->format, static_cast<hipStream_t>(stream));  // same tiles, grid and image as the VALU kernel
   } else {
     e = easu_launch(a, in->format, (flags & FSR1_FLAG_MATH_EXACT) != 0, s2, static_cast<hipStream_t>(stream));
   }
@@ -551,8 +538,7 @@ int fsr1_upscale_ex(const fsr1_image* in, const fsr1_image* intermediary, const 
   // :106 — viewport == input resource size == (renderWidth, renderHeight); output = display size
   FsrEasuCon(easu_con, easu_con + 4, easu_con + 8, easu_con + 12, p->render_width, p->render_height, p->render_width,
              p->render_height, (float)out->width, (float)out->height);
-  const uint32_t math = p->flags & (FSR1_FLAG_MATH_EXACT | FSR1_FLAG_MATH_PACKED_FP16 | FSR1_FLAG_NO_FAST_PATHS | FSR1_FLAG_EASU_MATRIX_PIPE |
-                                    FSR1_FLAG_EASU_NO_MATRIX_PIPE);
+  const uint32_t math = p->flags & (FSR1_FLAG_MATH_EXACT | FSR1_FLAG_MATH_PACKED_FP16 | FSR1_FLAG_NO_FAST_PATHS);
   const uint32_t rcas_opts = p->flags & (FSR1_FLAG_RCAS_DENOISE | FSR1_FLAG_RCAS_PASSTHROUGH_ALPHA);
   const uint32_t out_policy = p->flags & (FSR1_FLAG_OUTPUT_STREAMING | FSR1_FLAG_OUTPUT_CACHED);  // of the pass that writes `out`
   if (p->flags & ~(math | rcas_opts | out_policy)) return fail(FSR1_ERR_INVALID_ARGUMENT, "upscale: params.flags may only hold MATH_*, RCAS_* and OUTPUT_* bits");

@@ -107,79 +107,6 @@ __device__ __forceinline__ void easu_stage_footprint(const EasuLds& l, const Ima
   __syncthreads();
 }
 
-// ---- planar staging for the matrix-pipe variant (exact 2x, default arithmetic; csrc/fsr1_easu_mfma.hip) ----
-// Same phases 1 and 2, different LDS layout: colour as (R, G, B, 1.0) — the 1.0 is the A operand of the lane that
-// accumulates the weight sum (EasuAccMfma) — with luma in a plane of its own, so that the four lanes of an MFMA block read
-// four consecutive dwords of one texel and sixteen blocks read sixteen consecutive texels (conflict-free ds_read_b32), and
-// phase 2's five luma reads are unit-stride as well.  36 B per texel.
-constexpr int kEasuPlanarLdsPerTexel = 16 + 4 + 16;
-struct EasuLdsPlanar {
-  float4_t* tex;  // [n] R G B 1.0
-  float4_t* ana;  // [n] dirX dirY lenX^2+lenY^2 -
-  float* lum;     // [n] luma*2
-};
-__device__ __forceinline__ EasuLdsPlanar easu_lds_carve_planar(char* smem, int capacity_texels) {
-  EasuLdsPlanar l;
-  l.tex = reinterpret_cast<float4_t*>(smem);
-  l.ana = reinterpret_cast<float4_t*>(smem + (size_t)capacity_texels * 16);
-  l.lum = reinterpret_cast<float*>(smem + (size_t)capacity_texels * 32);
-  return l;
-}
-template <int FMT, int FW, int FH, int THREADS = 256>
-__device__ __forceinline__ void easu_stage_footprint_planar(const EasuLdsPlanar& l, const ImageView& in, const char* in_frame, int fx0, int fy0, int tid) {
-  typedef typename Pixel<FMT>::T texel_t;
-  constexpr int n = FW * FH - 1;  // the bottom-right corner texel is touched by no window
-  const int gy0 = min(max(fy0, 0), in.height - 1);
-  const char* const base = in_frame + (long long)gy0 * in.pitch;
-  const uint32_t pitch = (uint32_t)in.pitch;
-  auto stage = [&](int i, uint32_t off) {
-    const texel_t px = *reinterpret_cast<const texel_t*>(base + (size_t)off);
-    const float4_t c = Pixel<FMT>::load(px);
-    l.tex[i] = float4_t{c.x, c.y, c.z, 1.0f};
-    l.lum[i] = fmaf(c.z, 0.5f, fmaf(c.x, 0.5f, c.y));  // :363-366, as in easu_stage_footprint
-  };
-  if (fx0 >= 0 && fy0 >= 0 && fx0 + FW <= in.width && fy0 + FH <= in.height) {
-    const uint32_t x_off = (uint32_t)fx0 * (uint32_t)sizeof(texel_t);
-    for (int i = tid; i < n; i += THREADS) {
-      const int ly = i / FW;
-      stage(i, (uint32_t)ly * pitch + (uint32_t)(i - ly * FW) * (uint32_t)sizeof(texel_t) + x_off);
-    }
-  } else {
-    for (int i = tid; i < n; i += THREADS) {
-      const int ly = i / FW;
-      const int gy = min(max(fy0 + ly, 0), in.height - 1);
-      const int gx = min(max(fx0 + (i - ly * FW), 0), in.width - 1);
-      stage(i, (uint32_t)(gy - gy0) * pitch + (uint32_t)gx * (uint32_t)sizeof(texel_t));
-    }
-  }
-  __syncthreads();
-  constexpr int iw = FW - 2, m = iw * (FH - 2);
-  for (int j = tid; j < m; j += THREADS) {
-    const int y = j / iw;
-    const int i = (y + 1) * FW + (j - y * iw) + 1;
-    l.ana[i] = easu_analysis<false>(l.lum[i - FW], l.lum[i - 1], l.lum[i], l.lum[i + 1], l.lum[i + FW]);
-  }
-  __syncthreads();
-}
-
-// Dering clamp (:437) for the matrix-pipe variant.  Lane c (0, 1, 2) of a block holds (mn, mx) of channel c over the 2x2
-// texels f g j k; every lane of the block clamps its own pixel's R, G, B against lanes 0, 1, 2's bounds, fetched by the DPP
-// operand of v_max_f32 / v_min_f32 (quad_perm broadcast) — max then min, the reference's order, minNum / maxNum like
-// v_med3_f32 in easu_clamp.  s_nop 1: a DPP operand must not be read in the two wait states after the VALU write that
-// produced it, and the compiler does not look into inline assembly.
-__device__ __forceinline__ void easu_clamp_quad_dpp(float& r, float& g, float& b, float mn, float mx) {
-  asm volatile(
-      "s_nop 1\n\t"
-      "v_max_f32_dpp %0, %3, %0 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n\t"
-      "v_max_f32_dpp %1, %3, %1 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf\n\t"
-      "v_max_f32_dpp %2, %3, %2 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf\n\t"
-      "v_min_f32_dpp %0, %4, %0 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n\t"
-      "v_min_f32_dpp %1, %4, %1 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf\n\t"
-      "v_min_f32_dpp %2, %4, %2 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf"
-      : "+v"(r), "+v"(g), "+v"(b)
-      : "v"(mn), "v"(mx));
-}
-
 struct rgbf_t { float r, g, b; };
 
 // The FsrEasuF filter for one output pixel (ffx_fsr1.h:381-437 without the dering clamp): sub-texel position (ppx, ppy)
@@ -187,52 +114,8 @@ struct rgbf_t { float r, g, b; };
 // the four analyses through `ana(k)`, k = 0..3 for f, g, j, k (easu_analysis).  Returns aC * rcp(aW).  Everything up to
 // the `dirR < 1/32768` decision is evaluated in the reference's exact operation order: that decision (and floor() in
 // the caller) are the filter's only discontinuities.
-// Accumulators of the default arithmetic's tap loop — `aC += c*w; aW += w` (ffx_fsr1.h:268-272) as fused multiply-adds.
-//   EasuAccValu : four v_fma_f32 per tap on the lane's own (R, G, B, .) texel.
-//   EasuAccMfma : ONE v_mfma_f32_4x4x1_16b_f32 per tap for a block of four lanes whose pixels share the 12-tap window
-//                 (an exact-2x output quad, one pixel per lane).  Within a block the instruction computes
-//                 D[i][j] += A(lane 4b+i) * B(lane 4b+j) with D[i][j] in lane 4b+j, register i (layout confirmed on gfx950,
-//                 tools/ubench/mfma4x4_probe.hip): lane i supplies channel i of the tap's texel as A (lane 3: 1.0), lane j
-//                 its own weight as B, and lane j ends up with (aR, aG, aB, aW) of ITS pixel in acc.xyzw.  An f32 MFMA is
-//                 an fmaf chain, bit for bit (MI355X_MICROARCH.md "exact f32"), in the same tap order: same sums as
-//                 EasuAccValu, while the 48 multiply-adds per pixel leave the VALU for the otherwise idle matrix pipe.
-template <class Tex>
-struct EasuAccValu {
-  const Tex& tex;
-  float aR, aG, aB, aW;
-  __device__ __forceinline__ void first(int dx, int dy, float w) {
-    const float4_t c = tex(dx, dy);
-    aW = w;
-    aR = c.x * aW; aG = c.y * aW; aB = c.z * aW;
-  }
-  __device__ __forceinline__ void tap(int dx, int dy, float w) {
-    const float4_t c = tex(dx, dy);
-    aR = fmaf(c.x, w, aR); aG = fmaf(c.y, w, aG); aB = fmaf(c.z, w, aB);
-    aW += w;
-  }
-  __device__ __forceinline__ void result(float& r, float& g, float& b, float& w) const { r = aR; g = aG; b = aB; w = aW; }
-};
-template <class Chan>
-struct EasuAccMfma {
-  const Chan& chan;  // chan(dx, dy): this lane's channel (lane & 3: R, G, B, 1.0) of the tap's texel
-  float4_t acc;
-  __device__ __forceinline__ void first(int dx, int dy, float w) { acc = float4_t{0.f, 0.f, 0.f, 0.f}; tap(dx, dy, w); }
-  __device__ __forceinline__ void tap(int dx, int dy, float w) { acc = __builtin_amdgcn_mfma_f32_4x4x1f32(chan(dx, dy), w, acc, 0, 0, 0); }
-  __device__ __forceinline__ void result(float& r, float& g, float& b, float& w) const { r = acc.x; g = acc.y; b = acc.z; w = acc.w; }
-};
-
-template <bool EXACT, class Tex, class Ana, class Acc>
-__device__ __forceinline__ rgbf_t easu_filter_acc(const Tex& tex, const Ana& ana, float ppx, float ppy, Acc& acc);
-
 template <bool EXACT, class Tex, class Ana>
 __device__ __forceinline__ rgbf_t easu_filter(const Tex& tex, const Ana& ana, float ppx, float ppy) {
-  EasuAccValu<Tex> acc{tex, 0.f, 0.f, 0.f, 0.f};
-  return easu_filter_acc<EXACT>(tex, ana, ppx, ppy, acc);
-}
-
-// The filter with the default arithmetic's accumulation left to `acc` (EXACT does not use it: reference order on `tex`).
-template <bool EXACT, class Tex, class Ana, class Acc>
-__device__ __forceinline__ rgbf_t easu_filter_acc(const Tex& tex, const Ana& ana, float ppx, float ppy, Acc& acc) {
   const float omx = 1.0f - ppx, omy = 1.0f - ppy;
   // :381-386 bilinear accumulation of the 4 analyses (f,g,j,k), reference order:
   //   dir.x += dirX*w ; len += lenX*w ; dir.y += dirY*w ; len += lenY*w   for s,t,u,v in turn.
@@ -317,13 +200,21 @@ __device__ __forceinline__ rgbf_t easu_filter_acc(const Tex& tex, const Ana& ana
       const float wa = fmaf(k3, u, -1.0f);
       return base * (wa * wa);
     };
-    auto tap = [&](int dx, int dy, float ox, float s, float b) { acc.tap(dx, dy, weight(ox, s, b)); };
-    acc.first(0, -1, weight(ox0, sm, bm));  // the first tap starts the sums
+    auto tap = [&](int dx, int dy, float ox, float s, float b) {
+      const float4_t c = tex(dx, dy);
+      const float w = weight(ox, s, b);
+      aR = fmaf(c.x, w, aR); aG = fmaf(c.y, w, aG); aB = fmaf(c.z, w, aB);
+      aW += w;
+    };
+    {  // the first tap starts the sums
+      const float4_t c = tex(0, -1);
+      aW = weight(ox0, sm, bm);
+      aR = c.x * aW; aG = c.y * aW; aB = c.z * aW;
+    }
     tap(1, -1, ox1, sm, bm);
     tap(-1, 0, oxm, s0, b0); tap(0, 0, ox0, s0, b0); tap(1, 0, ox1, s0, b0); tap(2, 0, ox2, s0, b0);
     tap(-1, 1, oxm, s1, b1); tap(0, 1, ox0, s1, b1); tap(1, 1, ox1, s1, b1); tap(2, 1, ox2, s1, b1);
     tap(0, 2, ox0, s2, b2); tap(1, 2, ox1, s2, b2);
-    acc.result(aR, aG, aB, aW);
   }
   // :437 normalise (dering clamp is applied by the caller)
   const float rW = EXACT ? 1.0f / aW : __builtin_amdgcn_rcpf(aW);

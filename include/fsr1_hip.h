@@ -111,14 +111,7 @@ enum {
    * follows), RCAS and the fused launch STREAMING (their output is the pipeline's last image); fsr1_upscale sets
    * STREAMING on whichever pass writes `out`.  The pixels stored are the same either way. */
   FSR1_FLAG_OUTPUT_STREAMING = 1u << 9,
-  FSR1_FLAG_OUTPUT_CACHED = 1u << 10,
-  /* EASU, exact 2x, default arithmetic: run the 12-tap accumulation `aC += c*w; aW += w` (ffx_fsr1.h:268-272) on the
-   * matrix pipe — one v_mfma_f32_4x4x1 per tap for a quad of pixels sharing the window, an fmaf chain bit for bit — instead
-   * of four v_fma_f32 per pixel and tap (csrc/fsr1_easu_mfma.hip).  Same sums in the same order: the image is the one the
-   * VALU kernel writes (tests assert bit identity).  Ignored where it does not apply (other ratios, EXACT, packed fp16,
-   * colour stages).  DESIGN.md section 3.1 has the measurement that decides whether a build takes it by default. */
-  FSR1_FLAG_EASU_MATRIX_PIPE = 1u << 11,
-  FSR1_FLAG_EASU_NO_MATRIX_PIPE = 1u << 12
+  FSR1_FLAG_OUTPUT_CACHED = 1u << 10
 };
 
 typedef enum fsr1_status {

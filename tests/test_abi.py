@@ -43,13 +43,11 @@ def test_argument_validation(fsr):
     assert lib.fsr1_easu_dispatch(ctypes.byref(bad), ctypes.byref(bad), p, 0, None) == -2  # unsupported format
     ok = fsr.fsr1_image(0x1000, 16, 16, 0, 1, 0, 0)
     ok2 = fsr.fsr1_image(0x100000, 32, 32, 0, 1, 0, 0)
-    assert lib.fsr1_easu_dispatch(ctypes.byref(ok), ctypes.byref(ok2), p, 1 << 13, None) == -1  # unknown flag
+    assert lib.fsr1_easu_dispatch(ctypes.byref(ok), ctypes.byref(ok2), p, 1 << 11, None) == -1  # unknown flag
     assert b"unknown flag" in lib.fsr1_last_error()
     assert lib.fsr1_easu_dispatch(ctypes.byref(ok), ctypes.byref(ok2), p, (1 << 9) | (1 << 10), None) == -1  # store policies are exclusive
     assert b"OUTPUT" in lib.fsr1_last_error()
     assert lib.fsr1_easu_dispatch(ctypes.byref(ok), ctypes.byref(ok2), p, (1 << 4) | (1 << 5), None) == -1  # exclusive
-    assert lib.fsr1_easu_dispatch(ctypes.byref(ok), ctypes.byref(ok2), p, (1 << 11) | (1 << 12), None) == -1  # matrix pipe on and off
-    assert b"MATRIX_PIPE" in lib.fsr1_last_error()
     assert lib.fsr1_easu_dispatch(ctypes.byref(ok), ctypes.byref(ok), p, 0, None) == -1  # aliasing
     assert b"overlap" in lib.fsr1_last_error()
     assert lib.fsr1_easu_dispatch(ctypes.byref(ok), ctypes.byref(ok2), p, 0, None) == -1  # con0 scale = 0

@@ -592,71 +592,3 @@ def test_fused_exact_2x_quad_form(fsr, shape):
             raw = {torch.float16: torch.int16, torch.float32: torch.int32, torch.uint8: torch.uint8}[dt]
             assert torch.equal(outs[0].view(raw), outs[1].view(raw)), "quad form != generic fused (%s, flags %d)" % (dt, flags)
             assert torch.equal(outs[0].view(raw), two.view(raw)), "quad form != two dispatches (%s, flags %d)" % (dt, flags)
-
-
-# ------------------------------------------------------------------------------------------------
-# matrix-pipe accumulation (FSR1_FLAG_EASU_MATRIX_PIPE, csrc/fsr1_easu_mfma.hip)
-# ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("shape", [(960, 540), (97, 61), (33, 9), (32, 8), (31, 7), (1, 1)], ids=lambda s: "%dx%d" % s)
-def test_easu_matrix_pipe_is_bit_identical(fsr, shape):
-    """The exact-2x EASU kernel whose 12-tap accumulation runs as v_mfma_f32_4x4x1 (an fmaf chain in the same tap order)
-    writes the very image the VALU kernel writes: every storage format, the HDR square, batches with padded pitches, band
-    origins, image-like and hostile content."""
-    iw, ih = shape
-    ow, oh = 2 * iw, 2 * ih
-    on, off = fsr.FLAG_EASU_MATRIX_PIPE, fsr.FLAG_EASU_NO_MATRIX_PIPE
-    for k, make in ((1, frames.synthetic_frame), (2, frames.adversarial_frame)):
-        img16 = make(iw, ih, k=k, dtype=np.float16)
-        for hdr in (0, fsr.FLAG_HDR_SQUARE):
-            src = dev(img16)
-            a = torch.zeros(oh, ow, 4, dtype=torch.float16, device="cuda")
-            b = torch.full_like(a, -1.0)
-            fsr.easu(src, a, flags=off | hdr)
-            fsr.easu(src, b, flags=on | hdr)
-            assert torch.equal(a.view(torch.int16), b.view(torch.int16)), "rgba16f k=%d hdr=%d" % (k, hdr)
-        src32 = dev(img16.astype(np.float32))
-        a = torch.zeros(oh, ow, 4, dtype=torch.float32, device="cuda")
-        b = torch.full_like(a, -1.0)
-        fsr.easu(src32, a, flags=off)
-        fsr.easu(src32, b, flags=on)
-        assert torch.equal(a.view(torch.int32), b.view(torch.int32)), "rgba32f k=%d" % k
-    codes = dev(np.floor(np.clip(frames.synthetic_frame(iw, ih, k=3, dtype=np.float32), 0, 1) * 255 + 0.5).astype(np.uint8))
-    a = torch.zeros(oh, ow, 4, dtype=torch.uint8, device="cuda")
-    b = torch.full_like(a, 7)
-    fsr.easu(codes, a, flags=off)
-    fsr.easu(codes, b, flags=on)
-    assert torch.equal(a, b), "rgba8"
-
-
-def test_easu_matrix_pipe_batch_pitches_and_bands(fsr):
-    n, iw, ih = 3, 70, 37
-    ow, oh = 2 * iw, 2 * ih
-    on, off = fsr.FLAG_EASU_MATRIX_PIPE, fsr.FLAG_EASU_NO_MATRIX_PIPE
-    big_in = torch.zeros(n, ih + 3, iw + 5, 4, dtype=torch.float16, device="cuda")
-    src = big_in[:, :ih, :iw]
-    for f in range(n):
-        src[f].copy_(dev(frames.synthetic_frame(iw, ih, k=20 + f, dtype=np.float16)))
-    outs = []
-    for flags in (off, on):
-        big_out = torch.full((n, oh + 2, ow + 6, 4), -3.0, dtype=torch.float16, device="cuda")
-        dst = big_out[:, :oh, :ow]
-        fsr.easu(src, dst, flags=flags)
-        torch.cuda.synchronize()
-        assert float((big_out[:, oh:] != -3.0).sum()) == 0 and float((big_out[:, :, ow:] != -3.0).sum()) == 0  # padding untouched
-        outs.append(dst.clone())
-    assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16))
-    # a band of the output with an even origin keeps the exact-2x kernels: the matrix-pipe one equals the full frame's rows
-    con = fsr.FsrEasuCon(iw, ih, iw, ih, ow, oh)
-    full = outs[0][0]
-    for (y0, rows) in ((0, 20), (18, 31), (40, 34)):
-        band = torch.zeros(rows, ow, 4, dtype=torch.float16, device="cuda")
-        fsr.easu_band(src[0], band, con, origin=(0, y0), flags=on)
-        assert torch.equal(band.view(torch.int16), full[y0:y0 + rows].view(torch.int16)), (y0, rows)
-    # fsr1_upscale passes the choice through: two dispatches with the matrix-pipe EASU == the fused launch (VALU quads)
-    two = torch.zeros(oh, ow, 4, dtype=torch.float16, device="cuda")
-    mid = torch.zeros_like(two)
-    fus = torch.zeros_like(two)
-    fsr.easu(src[0].contiguous(), mid, flags=on)
-    fsr.rcas(mid, two, sharpness=0.25)
-    fsr.easu_rcas_fused(src[0].contiguous(), fus, sharpness=0.25)
-    assert torch.equal(two.view(torch.int16), fus.view(torch.int16))
