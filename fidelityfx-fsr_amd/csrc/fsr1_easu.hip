@@ -33,7 +33,7 @@ namespace fsr1 {
 // Bytes of dynamic LDS the kernel needs for a footprint capacity of fp_w x fp_h texels.
 size_t easu_lds_bytes(int fmt, int fp_w, int fp_h) {
   (void)fmt;
-  return (size_t)fp_w * fp_h * kEasuLdsPerTexel;
+  return (size_t)fp_w * fp_h * kEasuLdsPerTexel + (size_t)kTileH * 3 * sizeof(float4_t);  // footprint + the row-terms table of the generic kernel
 }
 
 // s2: launch the exact-2x variant (the caller has checked con0 and laid the grid out for the shifted tiles).

@@ -89,6 +89,19 @@ __global__ void __launch_bounds__(kThreads) easu_kernel(const EasuArgs a) {
   const int fw = min((int)floorf((float)(oxl + a.origin_x) * c0x + c0z) + 2 - fx0 + 1, a.fp_w);
   const int fh = min((int)floorf((float)(oyl + a.origin_y) * c0y + c0w) + 2 - fy0 + 1, a.fp_h);
   l.fw = fw;
+  // The row-only terms of the filter (ffx_fsr1.h:324-326 for y, the tap-row offsets and their squares, the footprint row of
+  // texel 'f') are the same for the 64 pixels of an output row: lanes 0 .. kTileH-1 evaluate them once per tile — the very
+  // operations every pixel would otherwise run — and park them behind the footprint; the staging barriers publish them.
+  float4_t* const rowt = reinterpret_cast<float4_t*>(smem + (size_t)a.fp_w * a.fp_h * kEasuLdsPerTexel);  // [kTileH][3]
+  if (tid < kTileH) {
+    float ppy = (float)(oy0 + tid + a.origin_y) * c0y + c0w;
+    const float fpy = floorf(ppy);
+    ppy -= fpy;
+    const EasuRowTerms y = easu_row_terms(ppy);
+    rowt[3 * tid + 0] = float4_t{y.ppy, y.omy, y.oym, y.oy2};
+    rowt[3 * tid + 1] = float4_t{y.sqm, y.sq0, y.sq1, y.sq2};
+    rowt[3 * tid + 2] = float4_t{y.oy0, as_f32((uint32_t)(((int)fpy - fy0) * fw)), 0.0f, 0.0f};
+  }
   easu_stage_footprint<FMT, COLOR, EXACT>(l, a.in, in_frame, fx0, fy0, fw, fh, tid, &a.color);
 
   // ---- phase 3: output pixels; a lane owns a column, a wave kTileH / 4 rows ----
@@ -107,13 +120,12 @@ __global__ void __launch_bounds__(kThreads) easu_kernel(const EasuArgs a) {
 
 #pragma unroll 1
   for (int r = 0; r < kTileH / 4; ++r) {
-    const int oy = oy0 + wave * (kTileH / 4) + r;
+    const int row = wave * (kTileH / 4) + r, oy = oy0 + row;
     if (oy >= a.out.height) break;
-    float ppy = (float)(oy + a.origin_y) * c0y + c0w;
-    const float fpy = floorf(ppy);
-    ppy -= fpy;
-    const int f_idx = ((int)fpy - fy0) * fw + lx;
-    const rgbf_t p = easu_pixel<EXACT>(l, f_idx, ppx, ppy);
+    const float4_t t0 = rowt[3 * row], t1 = rowt[3 * row + 1], t2 = rowt[3 * row + 2];
+    const EasuRowTerms yt = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w, t2.x};
+    const int f_idx = (int)as_u32(t2.y) + lx;
+    const rgbf_t p = easu_pixel<EXACT>(l, f_idx, ppx, yt);
     const EasuBounds m = easu_bounds(l, f_idx);
     texel_t* const dst = reinterpret_cast<texel_t*>(out_col + (long long)oy * a.out.pitch);
     if constexpr (COLOR) {

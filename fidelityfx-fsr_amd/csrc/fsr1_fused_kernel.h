@@ -46,6 +46,17 @@ __global__ void __launch_bounds__(kThreads) fused_kernel(const FusedArgs a) {
   l.fw = fw;
 
   const int tid = threadIdx.x;
+  // row-only terms of the EASU filter, once per apron row (as in easu_kernel): lanes 0 .. kMidH-1, published by the staging barriers
+  float4_t* const rowt = reinterpret_cast<float4_t*>(smem + (size_t)cap * kEasuLdsPerTexel + (((size_t)kMidW * kMidH * sizeof(texel_t) + 15) & ~(size_t)15));  // [kMidH][3]
+  if (tid < kMidH) {
+    float ppy = (float)(oy0 - 1 + tid + yorg) * c0y + c0w;  // :324-326
+    const float fpy = floorf(ppy);
+    ppy -= fpy;
+    const EasuRowTerms y = easu_row_terms(ppy);
+    rowt[3 * tid + 0] = float4_t{y.ppy, y.omy, y.oym, y.oy2};
+    rowt[3 * tid + 1] = float4_t{y.sqm, y.sq0, y.sq1, y.sq2};
+    rowt[3 * tid + 2] = float4_t{y.oy0, as_f32((uint32_t)(((int)fpy - fy0) * fw)), 0.0f, 0.0f};
+  }
   easu_stage_footprint<FMT, COLOR, EXACT>(l, a.in, a.in.base + (long long)frame * a.in.frame_stride, fx0, fy0, fw, fh, tid, &a.color);
 
   // ---- phase 3: EASU on the apron tile -> LDS, in the storage format (EASU runs with Sample.x = 0 when
@@ -56,11 +67,10 @@ __global__ void __launch_bounds__(kThreads) fused_kernel(const FusedArgs a) {
     const int oy = oy0 - 1 + my;
     texel_t px = Pixel<FMT>::zero();
     if (x_ok && oy >= ylo && oy <= yhi) {
-      float ppy = (float)(oy + yorg) * c0y + c0w;  // :324-326
-      const float fpy = floorf(ppy);
-      ppy -= fpy;
-      const int f_idx = ((int)fpy - fy0) * fw + lxf;
-      px = easu_resolve<FMT, EXACT>(easu_bounds(l, f_idx), easu_pixel<EXACT>(l, f_idx, ppx, ppy), false);
+      const float4_t t0 = rowt[3 * my], t1 = rowt[3 * my + 1], t2 = rowt[3 * my + 2];
+      const EasuRowTerms yt = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w, t2.x};
+      const int f_idx = (int)as_u32(t2.y) + lxf;
+      px = easu_resolve<FMT, EXACT>(easu_bounds(l, f_idx), easu_pixel<EXACT>(l, f_idx, ppx, yt), false);
     }
     mid[my * kMidW + mx] = px;
   };

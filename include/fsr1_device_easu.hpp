@@ -114,9 +114,33 @@ struct rgbf_t { float r, g, b; };
 // the four analyses through `ana(k)`, k = 0..3 for f, g, j, k (easu_analysis).  Returns aC * rcp(aW).  Everything up to
 // the `dirR < 1/32768` decision is evaluated in the reference's exact operation order: that decision (and floor() in
 // the caller) are the filter's only discontinuities.
+// The terms of the filter that depend on the sub-texel ROW position only.  Every pixel of an output row shares them, so a
+// tiled kernel may evaluate them once per row (easu_kernel: sixteen lanes, once per tile, parked in LDS) instead of once
+// per pixel; easu_filter(..., ppx, ppy) evaluates them in place.  Same operations on the same values either way.
+struct EasuRowTerms {
+  float ppy, omy, oym, oy2;    // sub-texel position (:324-326), 1 - ppy, and the tap-row offsets -1 - ppy, 2 - ppy
+  float sqm, sq0, sq1, sq2;    // squares of the four tap-row offsets oym, oy0 = 0 - ppy, oy1 = omy, oy2
+  float oy0;
+};
+__device__ __forceinline__ EasuRowTerms easu_row_terms(float ppy) {
+  EasuRowTerms y;
+  y.ppy = ppy; y.omy = 1.0f - ppy; y.oym = -1.0f - ppy; y.oy0 = 0.0f - ppy; y.oy2 = 2.0f - ppy;
+  y.sqm = y.oym * y.oym; y.sq0 = y.oy0 * y.oy0; y.sq1 = y.omy * y.omy; y.sq2 = y.oy2 * y.oy2;
+  return y;
+}
+
+template <bool EXACT, class Tex, class Ana>
+__device__ __forceinline__ rgbf_t easu_filter(const Tex& tex, const Ana& ana, float ppx, const EasuRowTerms& yt);
+
 template <bool EXACT, class Tex, class Ana>
 __device__ __forceinline__ rgbf_t easu_filter(const Tex& tex, const Ana& ana, float ppx, float ppy) {
-  const float omx = 1.0f - ppx, omy = 1.0f - ppy;
+  return easu_filter<EXACT>(tex, ana, ppx, easu_row_terms(ppy));
+}
+
+template <bool EXACT, class Tex, class Ana>
+__device__ __forceinline__ rgbf_t easu_filter(const Tex& tex, const Ana& ana, float ppx, const EasuRowTerms& yt) {
+  const float ppy = yt.ppy;
+  const float omx = 1.0f - ppx, omy = yt.omy;
   // :381-386 bilinear accumulation of the 4 analyses (f,g,j,k), reference order:
   //   dir.x += dirX*w ; len += lenX*w ; dir.y += dirY*w ; len += lenY*w   for s,t,u,v in turn.
   const float4_t af = ana(0), ag = ana(1), aj = ana(2), ak = ana(3);
@@ -158,7 +182,7 @@ __device__ __forceinline__ rgbf_t easu_filter(const Tex& tex, const Ana& ana, fl
   // :421-434 12 taps.  aC += c*w ; aW += w
   float aR = 0.f, aG = 0.f, aB = 0.f, aW = 0.f;
   const float oxm = -1.0f - ppx, ox0 = 0.0f - ppx, ox1 = 1.0f - ppx, ox2 = 2.0f - ppx;
-  const float oym = -1.0f - ppy, oy0 = 0.0f - ppy, oy1 = 1.0f - ppy, oy2 = 2.0f - ppy;
+  const float oym = yt.oym, oy0 = yt.oy0, oy1 = yt.omy, oy2 = yt.oy2;
   if (EXACT) {
     auto tap = [&](int dx, int dy, float offx, float offy) {
       const float4_t c = tex(dx, dy);
@@ -192,7 +216,7 @@ __device__ __forceinline__ rgbf_t easu_filter(const Tex& tex, const Ana& ana, fl
     const float dxx = dirx * dirx, dyy = diry * diry, dxy2 = 2.0f * (dirx * diry);
     const float q00 = fmaf(dxx, sx, dyy * sy), q11 = fmaf(dyy, sx, dxx * sy), q01 = dxy2 * (sx - sy);
     const float sm = q01 * oym, s0 = q01 * oy0, s1 = q01 * oy1, s2 = q01 * oy2;
-    const float bm = q11 * (oym * oym), b0 = q11 * (oy0 * oy0), b1 = q11 * (oy1 * oy1), b2 = q11 * (oy2 * oy2);
+    const float bm = q11 * yt.sqm, b0 = q11 * yt.sq0, b1 = q11 * yt.sq1, b2 = q11 * yt.sq2;
     const float k2 = 0.25f * clp * clp, k1 = -1.25f * clp, k3 = lob * clp;
     auto weight = [&](float ox, float s, float b) {
       const float u = sat(fmaf(ox, fmaf(q00, ox, s), b));
@@ -229,6 +253,13 @@ __device__ __forceinline__ rgbf_t easu_pixel(const EasuLds& l, int f_idx, float 
   const int fw = l.fw;
   return easu_filter<EXACT>([&](int dx, int dy) { return l.tex[f_idx + dy * fw + dx]; },
                             [&](int k) { return l.ana[f_idx + (k >> 1) * fw + (k & 1)]; }, ppx, ppy);
+}
+
+template <bool EXACT>
+__device__ __forceinline__ rgbf_t easu_pixel(const EasuLds& l, int f_idx, float ppx, const EasuRowTerms& yt) {
+  const int fw = l.fw;
+  return easu_filter<EXACT>([&](int dx, int dy) { return l.tex[f_idx + dy * fw + dx]; },
+                            [&](int k) { return l.ana[f_idx + (k >> 1) * fw + (k & 1)]; }, ppx, yt);
 }
 
 // Dering bounds (:416-419): per-channel min and max of the 2x2 block f g / j k whose top-left texel is f_idx.
