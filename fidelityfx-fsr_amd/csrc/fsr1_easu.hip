@@ -36,18 +36,34 @@ size_t easu_lds_bytes(int fmt, int fp_w, int fp_h) {
   return (size_t)fp_w * fp_h * kEasuLdsPerTexel + (size_t)kTileH * 3 * sizeof(float4_t);  // footprint + the row-terms table of the generic kernel
 }
 
+// Compile-time LDS pitches of the generic kernel's row-interleaved layout (default arithmetic, plain pass).  A tile's footprint
+// is 64 * (in / out) + 4 texels wide: 46 at 1.5x, 42 at 1.7x, 54 at 1.3x.  0: the dense run-time layout (any width).
+#ifndef FSR1_EASU_NO_PITCHED
+int easu_lds_pitch(int fp_w, bool exact, bool color) {
+  if (exact || color) return 0;
+  return fp_w <= 48 ? 48 : (fp_w <= 56 ? 56 : (fp_w <= 64 ? 64 : 0));
+}
+#else
+int easu_lds_pitch(int, bool, bool) { return 0; }
+#endif
+
 // s2: launch the exact-2x variant (the caller has checked con0 and laid the grid out for the shifted tiles).
 hipError_t easu_launch(const EasuArgs& a, int fmt, bool exact, bool s2, hipStream_t stream) {
   const bool hdr = (a.flags & FSR1_FLAG_HDR_SQUARE) != 0;
-#define FSR1_LAUNCH_H(F, E, S) return hdr ? easu_launch_one<F, E, false, F, S, true>(a, stream) : easu_launch_one<F, E, false, F, S, false>(a, stream)
+  int pitch = s2 ? 0 : easu_lds_pitch(a.fp_w, exact, false);
+  if (pitch && easu_lds_bytes(fmt, pitch, a.fp_h) > 40 * 1024) pitch = 0;  // (tall footprints of anisotropic ratios: keep the dense layout's occupancy)
+#define FSR1_LAUNCH_H(F, E, S, P) return hdr ? easu_launch_one<F, E, false, F, S, true, P>(a, stream) : easu_launch_one<F, E, false, F, S, false, P>(a, stream)
 #define FSR1_LAUNCH_E(F)                              \
   do {                                                \
     if (s2) {                                         \
-      if (exact) FSR1_LAUNCH_H(F, true, true);        \
-      FSR1_LAUNCH_H(F, false, true);                  \
+      if (exact) FSR1_LAUNCH_H(F, true, true, 0);     \
+      FSR1_LAUNCH_H(F, false, true, 0);               \
     }                                                 \
-    if (exact) FSR1_LAUNCH_H(F, true, false);         \
-    FSR1_LAUNCH_H(F, false, false);                   \
+    if (exact) FSR1_LAUNCH_H(F, true, false, 0);      \
+    if (pitch == 48) FSR1_LAUNCH_H(F, false, false, 48); \
+    if (pitch == 56) FSR1_LAUNCH_H(F, false, false, 56); \
+    if (pitch == 64) FSR1_LAUNCH_H(F, false, false, 64); \
+    FSR1_LAUNCH_H(F, false, false, 0);                \
   } while (0)
   switch (fmt) {
     case FSR1_FORMAT_RGBA16F: FSR1_LAUNCH_E(FSR1_FORMAT_RGBA16F);

@@ -7,6 +7,7 @@
 namespace fsr1 {
 
 size_t easu_lds_bytes(int fmt, int fp_w, int fp_h);
+int easu_lds_pitch(int fp_w, bool exact, bool color);
 
 // COLOR: colour stages fused in (fsr1_device_color.hpp) — FsrSrtmF on every input texel as it is loaded, and
 // FsrLfgaF / FsrSrtmInvF / FsrTepdC*F on the result before it is stored as FOUT.  COLOR = false is the plain pass
@@ -19,13 +20,16 @@ size_t easu_lds_bytes(int fmt, int fp_w, int fp_h);
 // arithmetic are done once per four pixels and (ppx, ppy) are compile-time constants, which folds the bilinear weights
 // and the tap offsets of easu_pixel (-12 % VALU instructions, same four-pixels-per-lane balance).  The arithmetic per
 // pixel is the same function on the same values: bit-identical to S2 = false (tests/test_gpu_parity.py).
-template <int FMT, bool EXACT, bool COLOR = false, int FOUT = FMT, bool S2 = false, bool HDR = false>
+// PITCH (generic variant only): 0 = dense LDS arrays of the tile's own footprint width; P = the row-interleaved layout with
+// the compile-time pitch P >= a.fp_w (easu_lds_carve_pitched): no LDS address arithmetic per tap row.
+template <int FMT, bool EXACT, bool COLOR = false, int FOUT = FMT, bool S2 = false, bool HDR = false, int PITCH = 0>
 __global__ void __launch_bounds__(kThreads) easu_kernel(const EasuArgs a) {
   typedef typename Pixel<FOUT>::T texel_t;
   constexpr bool kS2 = S2 && kTileH % 16 == 0;  // (other tile heights are tuning builds: the host never selects S2 for them)
   constexpr int kS2W = kTileW / 2 + 3, kS2H = kTileH / 2 + 3;  // footprint of every exact-2x tile
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  EasuLds l = easu_lds_carve(smem, kS2 ? kS2W * kS2H : a.fp_w * a.fp_h);
+  static_assert(!(S2 && PITCH), "the exact-2x variant has a compile-time footprint of its own");
+  EasuLds l = PITCH ? easu_lds_carve_pitched<PITCH ? PITCH : 1>(smem) : easu_lds_carve(smem, kS2 ? kS2W * kS2H : a.fp_w * a.fp_h);
 
   const int tiles_per_frame = a.tiles_x * a.tiles_y;
   const int t = xcd_swizzle(blockIdx.x, tiles_per_frame * a.frames);
@@ -88,11 +92,12 @@ __global__ void __launch_bounds__(kThreads) easu_kernel(const EasuArgs a) {
   const int fy0 = (int)floorf((float)gy0 * c0y + c0w) - 1;
   const int fw = min((int)floorf((float)(oxl + a.origin_x) * c0x + c0z) + 2 - fx0 + 1, a.fp_w);
   const int fh = min((int)floorf((float)(oyl + a.origin_y) * c0y + c0w) + 2 - fy0 + 1, a.fp_h);
-  l.fw = fw;
+  if (!PITCH) l.fw = fw;
+  const int row_stride = PITCH ? 2 * PITCH : fw;  // LDS texels between footprint rows
   // The row-only terms of the filter (ffx_fsr1.h:324-326 for y, the tap-row offsets and their squares, the footprint row of
   // texel 'f') are the same for the 64 pixels of an output row: lanes 0 .. kTileH-1 evaluate them once per tile — the very
   // operations every pixel would otherwise run — and park them behind the footprint; the staging barriers publish them.
-  float4_t* const rowt = reinterpret_cast<float4_t*>(smem + (size_t)a.fp_w * a.fp_h * kEasuLdsPerTexel);  // [kTileH][3]
+  float4_t* const rowt = reinterpret_cast<float4_t*>(smem + (size_t)(PITCH ? PITCH : a.fp_w) * a.fp_h * kEasuLdsPerTexel);  // [kTileH][3]
   if (tid < kTileH) {
     float ppy = (float)(oy0 + tid + a.origin_y) * c0y + c0w;
     const float fpy = floorf(ppy);
@@ -100,9 +105,9 @@ __global__ void __launch_bounds__(kThreads) easu_kernel(const EasuArgs a) {
     const EasuRowTerms y = easu_row_terms(ppy);
     rowt[3 * tid + 0] = float4_t{y.ppy, y.omy, y.oym, y.oy2};
     rowt[3 * tid + 1] = float4_t{y.sqm, y.sq0, y.sq1, y.sq2};
-    rowt[3 * tid + 2] = float4_t{y.oy0, as_f32((uint32_t)(((int)fpy - fy0) * fw)), 0.0f, 0.0f};
+    rowt[3 * tid + 2] = float4_t{y.oy0, as_f32((uint32_t)(((int)fpy - fy0) * row_stride)), 0.0f, 0.0f};
   }
-  easu_stage_footprint<FMT, COLOR, EXACT>(l, a.in, in_frame, fx0, fy0, fw, fh, tid, &a.color);
+  easu_stage_footprint<FMT, COLOR, EXACT, 0, 0, kThreads, PITCH>(l, a.in, in_frame, fx0, fy0, fw, fh, tid, &a.color);
 
   // ---- phase 3: output pixels; a lane owns a column, a wave kTileH / 4 rows ----
   const int ox = ox0 + lane;
@@ -138,12 +143,12 @@ __global__ void __launch_bounds__(kThreads) easu_kernel(const EasuArgs a) {
   }
 }
 
-template <int FMT, bool EXACT, bool COLOR, int FOUT, bool S2 = false, bool HDR = false>
+template <int FMT, bool EXACT, bool COLOR, int FOUT, bool S2 = false, bool HDR = false, int PITCH = 0>
 hipError_t easu_launch_one(const EasuArgs& a, hipStream_t stream) {
   const dim3 grid((unsigned)(a.tiles_x * a.tiles_y * a.frames)), block(kThreads);
-  const size_t lds = easu_lds_bytes(FMT, a.fp_w, a.fp_h);
-  if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&easu_kernel<FMT, EXACT, COLOR, FOUT, S2, HDR>), lds); e != hipSuccess) return e;
-  hipLaunchKernelGGL((easu_kernel<FMT, EXACT, COLOR, FOUT, S2, HDR>), grid, block, lds, stream, a);
+  const size_t lds = easu_lds_bytes(FMT, PITCH ? PITCH : a.fp_w, a.fp_h);
+  if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&easu_kernel<FMT, EXACT, COLOR, FOUT, S2, HDR, PITCH>), lds); e != hipSuccess) return e;
+  hipLaunchKernelGGL((easu_kernel<FMT, EXACT, COLOR, FOUT, S2, HDR, PITCH>), grid, block, lds, stream, a);
   return hipGetLastError();
 }
 

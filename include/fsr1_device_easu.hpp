@@ -30,6 +30,19 @@ __device__ __forceinline__ EasuLds easu_lds_carve(char* smem, int capacity_texel
   return l;
 }
 
+// Row-interleaved layout with a compile-time pitch P >= the footprint width: footprint row r is [P texels][P analyses], so
+// `tex`, `ana` and the row pitch `fw` = 2 P are compile-time offsets from one base — every tap, analysis and bounds read of a
+// pixel is then `ds_read_b128 v_base offset:imm`, with no address arithmetic per row (the dense layout of a run-time footprint
+// width costs a v_add per tap row and array: 14 per pixel in the generic kernel).
+template <int P>
+__device__ __forceinline__ EasuLds easu_lds_carve_pitched(char* smem) {
+  EasuLds l;
+  l.tex = reinterpret_cast<float4_t*>(smem);
+  l.ana = l.tex + P;
+  l.fw = 2 * P;
+  return l;
+}
+
 // FsrEasuSetF's terms for one position of the '+' neighbourhood  a / b c d / e  (ffx_fsr1.h:295-313), before the
 // bilinear weighting: they depend on the input image only, so the tiled form evaluates them once per input texel.
 // Reference order, no contraction.  Returns (dirX, dirY, lenX^2, lenY^2) when EXACT and (dirX, dirY, lenX^2 + lenY^2, 0)
@@ -60,7 +73,8 @@ __device__ __forceinline__ float4_t easu_analysis(float lA, float lB, float lC, 
 // The host guarantees fh * pitch < 2^31 (fsr1_api.hip), so texel addresses are a wave-uniform 64-bit row base plus a
 // 32-bit lane offset (global_load ... v_off, s[base]: no 64-bit vector arithmetic).
 // THREADS: threads of the workgroup, all of which must make the call (it contains two barriers).
-template <int FMT, bool PRE = false, bool EXACT = false, int FW = 0, int FH = 0, int THREADS = 256>
+// PITCH: 0 = dense arrays of fw-texel rows; P = the row-interleaved layout of easu_lds_carve_pitched<P> (l.fw = 2 P).
+template <int FMT, bool PRE = false, bool EXACT = false, int FW = 0, int FH = 0, int THREADS = 256, int PITCH = 0>
 __device__ __forceinline__ void easu_stage_footprint(const EasuLds& l, const ImageView& in, const char* in_frame, int fx0, int fy0,
                                                      int fw_rt, int fh_rt, int tid, const ColorArgs* color = nullptr) {
   typedef typename Pixel<FMT>::T texel_t;
@@ -72,25 +86,26 @@ __device__ __forceinline__ void easu_stage_footprint(const EasuLds& l, const Ima
   const int gy0 = min(max(fy0, 0), in.height - 1);  // first row the footprint reads
   const char* const base = in_frame + (long long)gy0 * in.pitch;
   const uint32_t pitch = (uint32_t)in.pitch;
-  auto stage = [&](int i, uint32_t off) {
+  constexpr int kRow = PITCH ? 2 * PITCH : 0;  // LDS row pitch of the interleaved layout
+  auto stage = [&](int i, int ly, uint32_t off) {
     const texel_t px = *reinterpret_cast<const texel_t*>(base + (size_t)off);
     float4_t c = Pixel<FMT>::load(px);
     if constexpr (PRE) c = color_prologue<EXACT>(*color, c);
     // :363-366  luma*2 = B*0.5 + (R*0.5 + G); the products by 0.5 are exact, so fusing them is too
-    l.tex[i] = float4_t{c.x, c.y, c.z, fmaf(c.z, 0.5f, fmaf(c.x, 0.5f, c.y))};
+    l.tex[PITCH ? ly * kRow + (i - ly * fw) : i] = float4_t{c.x, c.y, c.z, fmaf(c.z, 0.5f, fmaf(c.x, 0.5f, c.y))};
   };
   if (fx0 >= 0 && fy0 >= 0 && fx0 + fw <= in.width && fy0 + fh <= in.height) {  // wave-uniform: nothing to clamp (all tiles but the image's border)
     const uint32_t x_off = (uint32_t)fx0 * (uint32_t)sizeof(texel_t);
     for (int i = tid; i < n; i += THREADS) {
       const int ly = row_of(i);
-      stage(i, (uint32_t)ly * pitch + (uint32_t)(i - ly * fw) * (uint32_t)sizeof(texel_t) + x_off);
+      stage(i, ly, (uint32_t)ly * pitch + (uint32_t)(i - ly * fw) * (uint32_t)sizeof(texel_t) + x_off);
     }
   } else {
     for (int i = tid; i < n; i += THREADS) {
       const int ly = row_of(i);
       const int gy = min(max(fy0 + ly, 0), in.height - 1);
       const int gx = min(max(fx0 + (i - ly * fw), 0), in.width - 1);
-      stage(i, (uint32_t)(gy - gy0) * pitch + (uint32_t)gx * (uint32_t)sizeof(texel_t));
+      stage(i, ly, (uint32_t)(gy - gy0) * pitch + (uint32_t)gx * (uint32_t)sizeof(texel_t));
     }
   }
   __syncthreads();
@@ -101,8 +116,9 @@ __device__ __forceinline__ void easu_stage_footprint(const EasuLds& l, const Ima
   const float* const lum = reinterpret_cast<const float*>(l.tex) + 3;  // luma of texel i at lum[4 * i]
   for (int j = tid; j < m; j += THREADS) {
     const int y = FW ? j / (FW - 2) : (int)(((float)j + 0.5f) * inv_iw);
-    const int i = (y + 1) * fw + (j - y * iw) + 1;
-    l.ana[i] = easu_analysis<EXACT>(lum[4 * (i - fw)], lum[4 * (i - 1)], lum[4 * i], lum[4 * (i + 1)], lum[4 * (i + fw)]);
+    const int rs = PITCH ? kRow : fw;  // row stride of the layout
+    const int i = (y + 1) * rs + (j - y * iw) + 1;
+    l.ana[i] = easu_analysis<EXACT>(lum[4 * (i - rs)], lum[4 * (i - 1)], lum[4 * i], lum[4 * (i + 1)], lum[4 * (i + rs)]);
   }
   __syncthreads();
 }
@@ -258,8 +274,12 @@ __device__ __forceinline__ rgbf_t easu_pixel(const EasuLds& l, int f_idx, float 
 template <bool EXACT>
 __device__ __forceinline__ rgbf_t easu_pixel(const EasuLds& l, int f_idx, float ppx, const EasuRowTerms& yt) {
   const int fw = l.fw;
-  return easu_filter<EXACT>([&](int dx, int dy) { return l.tex[f_idx + dy * fw + dx]; },
-                            [&](int k) { return l.ana[f_idx + (k >> 1) * fw + (k & 1)]; }, ppx, yt);
+  // based at the window's top-left texel (-1, -1): with a compile-time row pitch every tap is base + a non-negative
+  // immediate offset (the DS offset field is unsigned: taps above / left of 'f' would otherwise need bases of their own)
+  const float4_t* const w0 = l.tex + (f_idx - fw - 1);
+  const float4_t* const a0 = w0 + (l.ana - l.tex);  // (a compile-time distance in the pitched layout)
+  return easu_filter<EXACT>([&](int dx, int dy) { return w0[(dy + 1) * fw + (dx + 1)]; },
+                            [&](int k) { return a0[((k >> 1) + 1) * fw + (k & 1) + 1]; }, ppx, yt);
 }
 
 // Dering bounds (:416-419): per-channel min and max of the 2x2 block f g / j k whose top-left texel is f_idx.
@@ -286,7 +306,8 @@ __device__ __forceinline__ EasuBounds easu_bounds(float4_t cf, float4_t cg, floa
 
 __device__ __forceinline__ EasuBounds easu_bounds(const EasuLds& l, int f_idx) {
   const int fw = l.fw;
-  return easu_bounds(l.tex[f_idx], l.tex[f_idx + 1], l.tex[f_idx + fw], l.tex[f_idx + fw + 1]);
+  const float4_t* const w0 = l.tex + (f_idx - fw - 1);  // the window's top-left texel, as in easu_pixel: one base for every read
+  return easu_bounds(w0[fw + 1], w0[fw + 2], w0[2 * fw + 1], w0[2 * fw + 2]);
 }
 
 // Dering clamp in binary32 (:437 `min(max4, max(min4, pix))`) + optional `c *= c` (FSR_Pass.hlsl:78-79): the filter's
