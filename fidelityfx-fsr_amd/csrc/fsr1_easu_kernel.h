@@ -29,7 +29,7 @@ __global__ void __launch_bounds__(kThreads) easu_kernel(const EasuArgs a) {
   constexpr int kS2W = kTileW / 2 + 3, kS2H = kTileH / 2 + 3;  // footprint of every exact-2x tile
   extern __shared__ __attribute__((aligned(16))) char smem[];
   static_assert(!(S2 && PITCH), "the exact-2x variant has a compile-time footprint of its own");
-  EasuLds l = PITCH ? easu_lds_carve_pitched<PITCH ? PITCH : 1>(smem) : easu_lds_carve(smem, kS2 ? kS2W * kS2H : a.fp_w * a.fp_h);
+  EasuLds l = PITCH ? easu_lds_carve_pitched<PITCH ? PITCH : 4>(smem) : easu_lds_carve(smem, kS2 ? kS2W * kS2H : a.fp_w * a.fp_h);
 
   const int tiles_per_frame = a.tiles_x * a.tiles_y;
   const int t = xcd_swizzle(blockIdx.x, tiles_per_frame * a.frames);
@@ -93,24 +93,24 @@ __global__ void __launch_bounds__(kThreads) easu_kernel(const EasuArgs a) {
   const int fw = min((int)floorf((float)(oxl + a.origin_x) * c0x + c0z) + 2 - fx0 + 1, a.fp_w);
   const int fh = min((int)floorf((float)(oyl + a.origin_y) * c0y + c0w) + 2 - fy0 + 1, a.fp_h);
   if (!PITCH) l.fw = fw;
-  const int row_stride = PITCH ? 2 * PITCH : fw;  // LDS texels between footprint rows
+  const int row_stride = PITCH ? 2 * PITCH + PITCH / 4 : fw;  // LDS records between footprint rows
   // The row-only terms of the filter (ffx_fsr1.h:324-326 for y, the tap-row offsets and their squares, the footprint row of
   // texel 'f') are the same for the 64 pixels of an output row: lanes 0 .. kTileH-1 evaluate them once per tile — the very
   // operations every pixel would otherwise run — and park them behind the footprint; the staging barriers publish them.
-  float4_t* const rowt = reinterpret_cast<float4_t*>(smem + (size_t)(PITCH ? PITCH : a.fp_w) * a.fp_h * kEasuLdsPerTexel);  // [kTileH][3]
+  float4_t* const rowt = reinterpret_cast<float4_t*>(smem + easu_lds_region_bytes((size_t)(PITCH ? PITCH : a.fp_w) * a.fp_h));  // [kTileH][2]
   if (tid < kTileH) {
     float ppy = (float)(oy0 + tid + a.origin_y) * c0y + c0w;
     const float fpy = floorf(ppy);
     ppy -= fpy;
     const EasuRowTerms y = easu_row_terms(ppy);
-    rowt[3 * tid + 0] = float4_t{y.ppy, y.omy, y.oym, y.oy2};
-    rowt[3 * tid + 1] = float4_t{y.sqm, y.sq0, y.sq1, y.sq2};
-    rowt[3 * tid + 2] = float4_t{y.oy0, as_f32((uint32_t)(((int)fpy - fy0) * row_stride)), 0.0f, 0.0f};
+    rowt[2 * tid + 0] = float4_t{y.ppy, y.oym, y.oy2, as_f32((uint32_t)(((int)fpy - fy0) * row_stride))};
+    rowt[2 * tid + 1] = float4_t{y.sqm, y.sq0, y.sq1, y.sq2};
   }
   easu_stage_footprint<FMT, COLOR, EXACT, 0, 0, kThreads, PITCH>(l, a.in, in_frame, fx0, fy0, fw, fh, tid, &a.color);
 
-  // ---- phase 3: output pixels; a lane owns a column, a wave kTileH / 4 rows ----
-  const int ox = ox0 + lane;
+  // ---- phase 3: output pixels; a lane owns a column, a wave kTileH / 4 rows.  Which column: easu_lane_column — sixteen
+  //      consecutive columns per LDS lane group, so that a group's texels stay within sixteen records (no bank conflicts) ----
+  const int ox = ox0 + easu_lane_column(lane);
   if (ox >= a.out.width) return;
   char* const out_col = a.out.base + (long long)frame * a.out.frame_stride + (size_t)ox * sizeof(texel_t);
   // :324-326 (x part, shared by this lane's rows)
@@ -127,11 +127,11 @@ __global__ void __launch_bounds__(kThreads) easu_kernel(const EasuArgs a) {
   for (int r = 0; r < kTileH / 4; ++r) {
     const int row = wave * (kTileH / 4) + r, oy = oy0 + row;
     if (oy >= a.out.height) break;
-    const float4_t t0 = rowt[3 * row], t1 = rowt[3 * row + 1], t2 = rowt[3 * row + 2];
-    const EasuRowTerms yt = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w, t2.x};
-    const int f_idx = (int)as_u32(t2.y) + lx;
-    const rgbf_t p = easu_pixel<EXACT>(l, f_idx, ppx, yt);
-    const EasuBounds m = easu_bounds(l, f_idx);
+    const float4_t t0 = rowt[2 * row], t1 = rowt[2 * row + 1];
+    const EasuRowTerms yt = {t0.x, 1.0f - t0.x, t0.y, t0.z, t1.x, t1.y, t1.z, t1.w, 0.0f - t0.x};
+    const int f_idx = (int)as_u32(t0.w) + lx;
+    EasuBounds m;
+    const rgbf_t p = easu_pixel_with_bounds<EXACT>(l, f_idx, ppx, yt, m);
     texel_t* const dst = reinterpret_cast<texel_t*>(out_col + (long long)oy * a.out.pitch);
     if constexpr (COLOR) {
       rgbf_t q = easu_clamp<EXACT>(m, p, hdr);

@@ -22,7 +22,7 @@ __global__ void __launch_bounds__(kThreads) fused_kernel(const FusedArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int cap = a.fp_w * a.fp_h;
   EasuLds l = easu_lds_carve(smem, cap);
-  texel_t* const mid = reinterpret_cast<texel_t*>(smem + (size_t)cap * kEasuLdsPerTexel);  // [kMidH][kMidW]
+  texel_t* const mid = reinterpret_cast<texel_t*>(smem + easu_lds_region_bytes(cap));  // [kMidH][kMidW]
 
   const int tiles_per_frame = a.tiles_x * a.tiles_y;
   const int t = xcd_swizzle(blockIdx.x, tiles_per_frame * a.frames);
@@ -47,15 +47,14 @@ __global__ void __launch_bounds__(kThreads) fused_kernel(const FusedArgs a) {
 
   const int tid = threadIdx.x;
   // row-only terms of the EASU filter, once per apron row (as in easu_kernel): lanes 0 .. kMidH-1, published by the staging barriers
-  float4_t* const rowt = reinterpret_cast<float4_t*>(smem + (size_t)cap * kEasuLdsPerTexel + (((size_t)kMidW * kMidH * sizeof(texel_t) + 15) & ~(size_t)15));  // [kMidH][3]
+  float4_t* const rowt = reinterpret_cast<float4_t*>(smem + easu_lds_region_bytes(cap) + (((size_t)kMidW * kMidH * sizeof(texel_t) + 15) & ~(size_t)15));  // [kMidH][2]
   if (tid < kMidH) {
     float ppy = (float)(oy0 - 1 + tid + yorg) * c0y + c0w;  // :324-326
     const float fpy = floorf(ppy);
     ppy -= fpy;
     const EasuRowTerms y = easu_row_terms(ppy);
-    rowt[3 * tid + 0] = float4_t{y.ppy, y.omy, y.oym, y.oy2};
-    rowt[3 * tid + 1] = float4_t{y.sqm, y.sq0, y.sq1, y.sq2};
-    rowt[3 * tid + 2] = float4_t{y.oy0, as_f32((uint32_t)(((int)fpy - fy0) * fw)), 0.0f, 0.0f};
+    rowt[2 * tid + 0] = float4_t{y.ppy, y.oym, y.oy2, as_f32((uint32_t)(((int)fpy - fy0) * fw))};
+    rowt[2 * tid + 1] = float4_t{y.sqm, y.sq0, y.sq1, y.sq2};
   }
   easu_stage_footprint<FMT, COLOR, EXACT>(l, a.in, a.in.base + (long long)frame * a.in.frame_stride, fx0, fy0, fw, fh, tid, &a.color);
 
@@ -67,10 +66,12 @@ __global__ void __launch_bounds__(kThreads) fused_kernel(const FusedArgs a) {
     const int oy = oy0 - 1 + my;
     texel_t px = Pixel<FMT>::zero();
     if (x_ok && oy >= ylo && oy <= yhi) {
-      const float4_t t0 = rowt[3 * my], t1 = rowt[3 * my + 1], t2 = rowt[3 * my + 2];
-      const EasuRowTerms yt = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w, t2.x};
-      const int f_idx = (int)as_u32(t2.y) + lxf;
-      px = easu_resolve<FMT, EXACT>(easu_bounds(l, f_idx), easu_pixel<EXACT>(l, f_idx, ppx, yt), false);
+      const float4_t t0 = rowt[2 * my], t1 = rowt[2 * my + 1];
+      const EasuRowTerms yt = {t0.x, 1.0f - t0.x, t0.y, t0.z, t1.x, t1.y, t1.z, t1.w, 0.0f - t0.x};
+      const int f_idx = (int)as_u32(t0.w) + lxf;
+      EasuBounds m;
+      const rgbf_t p = easu_pixel_with_bounds<EXACT>(l, f_idx, ppx, yt, m);
+      px = easu_resolve<FMT, EXACT>(m, p, false);
     }
     mid[my * kMidW + mx] = px;
   };
@@ -85,9 +86,10 @@ __global__ void __launch_bounds__(kThreads) fused_kernel(const FusedArgs a) {
   {
     float ppx;
     int lxf;
-    const bool x_ok = x_position(lane, ppx, lxf);
+    const int mx = easu_lane_column(lane);  // sixteen consecutive columns per LDS lane group: no bank conflicts on the window reads
+    const bool x_ok = x_position(mx, ppx, lxf);
 #pragma unroll 1
-    for (int my = wave; my < kMidH; my += 4) easu_to_mid(lane, my, ppx, lxf, x_ok);
+    for (int my = wave; my < kMidH; my += 4) easu_to_mid(mx, my, ppx, lxf, x_ok);
   }
   // leftover columns: 2 x kMidH pixels, given to the last wave (it has the fewest rows above when kMidH % 4 == 2)
   if (wave == 3) {

@@ -21,7 +21,7 @@ constexpr int kFs2OutW = 62, kFs2MidW = 64, kFs2FpW = 35;
 
 size_t fused_s2_lds_bytes(int fmt, int qh) {
   const size_t texel = fmt == FSR1_FORMAT_RGBA32F ? 16 : (fmt == FSR1_FORMAT_RGBA16F ? 8 : 4);
-  return (size_t)kFs2FpW * (qh + 3) * kEasuLdsPerTexel + (size_t)kFs2MidW * 2 * qh * texel;
+  return easu_lds_region_bytes((size_t)kFs2FpW * (qh + 3)) + (size_t)kFs2MidW * 2 * qh * texel;
 }
 
 void fused_s2_geometry(int width, int height, int qh, int* tiles_x, int* tiles_y) {
@@ -36,7 +36,7 @@ __global__ void __launch_bounds__(kThreads) fused_s2_kernel(const FusedArgs a) {
   constexpr int kFpH = QH + 3, kOutH = 2 * QH - 2;  // (the apron tile is 2 QH rows tall)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   EasuLds l = easu_lds_carve(smem, kFs2FpW * kFpH);
-  texel_t* const mid = reinterpret_cast<texel_t*>(smem + (size_t)kFs2FpW * kFpH * kEasuLdsPerTexel);  // [kMidH][64]
+  texel_t* const mid = reinterpret_cast<texel_t*>(smem + easu_lds_region_bytes(kFs2FpW * kFpH));  // [kMidH][64]
 
   const int tiles_per_frame = a.tiles_x * a.tiles_y;
   const int t = xcd_swizzle(blockIdx.x, tiles_per_frame * a.frames);
