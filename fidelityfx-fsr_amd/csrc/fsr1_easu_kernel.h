@@ -29,7 +29,7 @@ __global__ void __launch_bounds__(kThreads) easu_kernel(const EasuArgs a) {
   constexpr int kS2W = kTileW / 2 + 3, kS2H = kTileH / 2 + 3;  // footprint of every exact-2x tile
   extern __shared__ __attribute__((aligned(16))) char smem[];
   static_assert(!(S2 && PITCH), "the exact-2x variant has a compile-time footprint of its own");
-  EasuLds l = PITCH ? easu_lds_carve_pitched<PITCH ? PITCH : 4>(smem) : easu_lds_carve(smem, kS2 ? kS2W * kS2H : a.fp_w * a.fp_h);
+  EasuLds l = PITCH ? easu_lds_carve_pitched<PITCH ? PITCH : 1>(smem) : easu_lds_carve(smem, kS2 ? kS2W * kS2H : a.fp_w * a.fp_h);
 
   const int tiles_per_frame = a.tiles_x * a.tiles_y;
   const int t = xcd_swizzle(blockIdx.x, tiles_per_frame * a.frames);
@@ -93,7 +93,7 @@ __global__ void __launch_bounds__(kThreads) easu_kernel(const EasuArgs a) {
   const int fw = min((int)floorf((float)(oxl + a.origin_x) * c0x + c0z) + 2 - fx0 + 1, a.fp_w);
   const int fh = min((int)floorf((float)(oyl + a.origin_y) * c0y + c0w) + 2 - fy0 + 1, a.fp_h);
   if (!PITCH) l.fw = fw;
-  const int row_stride = PITCH ? 2 * PITCH + PITCH / 4 : fw;  // LDS records between footprint rows
+  const int row_stride = PITCH ? 2 * PITCH : fw;  // LDS records between footprint rows
   // The row-only terms of the filter (ffx_fsr1.h:324-326 for y, the tap-row offsets and their squares, the footprint row of
   // texel 'f') are the same for the 64 pixels of an output row: lanes 0 .. kTileH-1 evaluate them once per tile — the very
   // operations every pixel would otherwise run — and park them behind the footprint; the staging barriers publish them.

@@ -13,17 +13,17 @@
 
 namespace fsr1 {
 
-// LDS bytes per footprint texel: fp32 texel (R, G, B, luma*2) + analysis + luma*2 once more in a plane of its own — phase 2
-// reads five lumas per texel with ds_read_b32, which from the 16-byte texel records is a stride of four dwords (4-way bank
-// conflicts) and from the plane unit stride.
-constexpr int kEasuLdsPerTexel = 16 + 16 + 4;
-// bytes of the staged footprint, padded so that whatever a kernel carves behind it stays 16-byte aligned
-__host__ __device__ constexpr size_t easu_lds_region_bytes(size_t capacity_texels) { return (capacity_texels * kEasuLdsPerTexel + 15) & ~(size_t)15; }
+// LDS bytes per footprint texel: fp32 texel (R,G,B,luma*2) + analysis
+// (a separate luma plane makes phase 2's five ds_read_b32 conflict-free — from the 16-byte records they are four dwords apart:
+// 4-way bank conflicts — but its 4 bytes per texel cost a resident workgroup at 1.3x and the exact-2x kernels ran 1-2 % slower
+// with it: profiles/ab_r03/r3c3_generic_easu_lane_columns_ab.log; phase 2 is a twentieth of the kernel)
+constexpr int kEasuLdsPerTexel = 16 + 16;
+// bytes of the staged footprint (a multiple of 16: whatever a kernel carves behind it stays aligned)
+__host__ __device__ constexpr size_t easu_lds_region_bytes(size_t capacity_texels) { return capacity_texels * kEasuLdsPerTexel; }
 
 struct EasuLds {
   float4_t* tex;  // [n] R G B luma*2
   float4_t* ana;  // [n] FsrEasuSetF terms of the '+' around the texel: dirX dirY lenX^2 lenY^2 (EXACT) / dirX dirY lenX^2+lenY^2 - (default)
-  float* lum;     // luma*2 plane (dense layout: [n], same indices; pitched layout: a row's P floats behind its analyses)
   int fw;         // row pitch of tex / ana in texels (dense layout: the footprint width)
 };
 
@@ -31,23 +31,20 @@ __device__ __forceinline__ EasuLds easu_lds_carve(char* smem, int capacity_texel
   EasuLds l;
   l.tex = reinterpret_cast<float4_t*>(smem);
   l.ana = reinterpret_cast<float4_t*>(smem + (size_t)capacity_texels * 16);
-  l.lum = reinterpret_cast<float*>(smem + (size_t)capacity_texels * 32);
   l.fw = 0;  // the caller sets the footprint width
   return l;
 }
 
-// Row-interleaved layout with a compile-time pitch P >= the footprint width: footprint row r is [P texels][P analyses]
-// [P lumas], so `tex`, `ana` and the row pitch `fw` = 2 P + P / 4 records are compile-time offsets from one base — every tap, analysis and bounds read of a
+// Row-interleaved layout with a compile-time pitch P >= the footprint width: footprint row r is [P texels][P analyses], so
+// `tex`, `ana` and the row pitch `fw` = 2 P are compile-time offsets from one base — every tap, analysis and bounds read of a
 // pixel is then `ds_read_b128 v_base offset:imm`, with no address arithmetic per row (the dense layout of a run-time footprint
 // width costs a v_add per tap row and array: 14 per pixel in the generic kernel).
 template <int P>
 __device__ __forceinline__ EasuLds easu_lds_carve_pitched(char* smem) {
-  static_assert(P % 4 == 0, "a row's luma plane is P / 4 records");
   EasuLds l;
   l.tex = reinterpret_cast<float4_t*>(smem);
   l.ana = l.tex + P;
-  l.lum = reinterpret_cast<float*>(l.tex + 2 * P);
-  l.fw = 2 * P + P / 4;  // row r: [P texels][P analyses][P lumas]
+  l.fw = 2 * P;  // row r: [P texels][P analyses]
   return l;
 }
 
@@ -110,16 +107,13 @@ __device__ __forceinline__ void easu_stage_footprint(const EasuLds& l, const Ima
   const int gy0 = min(max(fy0, 0), in.height - 1);  // first row the footprint reads
   const char* const base = in_frame + (long long)gy0 * in.pitch;
   const uint32_t pitch = (uint32_t)in.pitch;
-  constexpr int kRow = PITCH ? 2 * PITCH + PITCH / 4 : 0;  // LDS row pitch (records) of the interleaved layout
-  const int lp = PITCH ? 4 * kRow : fw;                      // row pitch of the luma plane (floats)
+  constexpr int kRow = PITCH ? 2 * PITCH : 0;  // LDS row pitch (records) of the interleaved layout
   auto stage = [&](int i, int ly, uint32_t off) {
     const texel_t px = *reinterpret_cast<const texel_t*>(base + (size_t)off);
     float4_t c = Pixel<FMT>::load(px);
     if constexpr (PRE) c = color_prologue<EXACT>(*color, c);
     // :363-366  luma*2 = B*0.5 + (R*0.5 + G); the products by 0.5 are exact, so fusing them is too
-    const float luma = fmaf(c.z, 0.5f, fmaf(c.x, 0.5f, c.y));
-    l.tex[PITCH ? ly * kRow + (i - ly * fw) : i] = float4_t{c.x, c.y, c.z, luma};
-    l.lum[PITCH ? ly * lp + (i - ly * fw) : i] = luma;
+    l.tex[PITCH ? ly * kRow + (i - ly * fw) : i] = float4_t{c.x, c.y, c.z, fmaf(c.z, 0.5f, fmaf(c.x, 0.5f, c.y))};
   };
   if (fx0 >= 0 && fy0 >= 0 && fx0 + fw <= in.width && fy0 + fh <= in.height) {  // wave-uniform: nothing to clamp (all tiles but the image's border)
     const uint32_t x_off = (uint32_t)fx0 * (uint32_t)sizeof(texel_t);
@@ -140,12 +134,12 @@ __device__ __forceinline__ void easu_stage_footprint(const EasuLds& l, const Ima
   //      1..fw-2, rows 1..fh-2 of the footprint (every neighbour of those lies inside it, so nothing is clamped). ----
   const int iw = fw - 2, m = iw * (fh - 2);
   const float inv_iw = 1.0f / (float)iw;
+  const float* const lum = reinterpret_cast<const float*>(l.tex) + 3;  // luma of texel i at lum[4 * i]
   for (int j = tid; j < m; j += THREADS) {
     const int y = FW ? j / (FW - 2) : (int)(((float)j + 0.5f) * inv_iw);
-    const int x = (j - y * iw) + 1;
-    const int rs = PITCH ? kRow : fw;  // row stride of the records
-    const float* const c = l.lum + (y + 1) * lp + x;  // unit stride across lanes: no bank conflicts
-    l.ana[(y + 1) * rs + x] = easu_analysis<EXACT>(c[-lp], c[-1], c[0], c[1], c[lp]);
+    const int rs = PITCH ? kRow : fw;  // row stride of the layout
+    const int i = (y + 1) * rs + (j - y * iw) + 1;
+    l.ana[i] = easu_analysis<EXACT>(lum[4 * (i - rs)], lum[4 * (i - 1)], lum[4 * i], lum[4 * (i + 1)], lum[4 * (i + rs)]);
   }
   __syncthreads();
 }
