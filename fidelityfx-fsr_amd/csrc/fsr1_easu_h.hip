@@ -15,7 +15,6 @@
 // half2 pairs, the operand shape of the two-taps-per-op FsrEasuTapH.  Position arithmetic stays fp32 (:513-516).
 #include "fsr1_device.h"
 #include "fsr1_device_half.hpp"
-#include "fsr1_device_easu.hpp"  // easu_lane_column
 
 namespace fsr1 {
 
@@ -84,7 +83,7 @@ __global__ void __launch_bounds__(kThreads) easu_h_kernel(const EasuArgs a) {
   const int fh = min((int)floorf((float)oyl * c0y + c0w) + 2 - fy0 + 1, a.fp_h);
   easu_h_stage<0, 0>(l, a.in, in_frame, fx0, fy0, fw, fh, tid);
 
-  const int ox = ox0 + easu_lane_column(lane);  // sixteen consecutive columns per LDS lane group: no bank conflicts on the window reads
+  const int ox = ox0 + lane;
   if (ox >= a.out.width) return;
   char* const out_col = a.out.base + (long long)frame * a.out.frame_stride + (size_t)ox * sizeof(half4_t);
   float ppx = (float)ox * c0x + c0z;  // :513-515

@@ -123,11 +123,19 @@ __global__ void __launch_bounds__(kThreads) easu_kernel(const EasuArgs a) {
   const bool hdr = COLOR ? (a.flags & FSR1_FLAG_HDR_SQUARE) != 0 : HDR;
   const bool stream = (a.flags & FSR1_FLAG_OUTPUT_STREAMING) != 0;
 
+  // the row terms are read one row ahead: the window's address depends on them, and two LDS round trips in a row would
+  // otherwise open every pixel
+  float4_t n0 = rowt[2 * (wave * (kTileH / 4))], n1 = rowt[2 * (wave * (kTileH / 4)) + 1];
 #pragma unroll 1
   for (int r = 0; r < kTileH / 4; ++r) {
     const int row = wave * (kTileH / 4) + r, oy = oy0 + row;
     if (oy >= a.out.height) break;
-    const float4_t t0 = rowt[2 * row], t1 = rowt[2 * row + 1];
+    const float4_t t0 = n0, t1 = n1;
+    {
+      const int nrow = min(row + 1, kTileH - 1);
+      n0 = rowt[2 * nrow];
+      n1 = rowt[2 * nrow + 1];
+    }
     const EasuRowTerms yt = {t0.x, 1.0f - t0.x, t0.y, t0.z, t1.x, t1.y, t1.z, t1.w, 0.0f - t0.x};
     const int f_idx = (int)as_u32(t0.w) + lx;
     EasuBounds m;

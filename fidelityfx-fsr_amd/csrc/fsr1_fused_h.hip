@@ -8,7 +8,6 @@
 // path; at 4K the apron recompute (+16 % of FsrEasuH) costs more than the intermediary's traffic saves.
 #include "fsr1_device.h"
 #include "fsr1_device_half.hpp"
-#include "fsr1_device_easu.hpp"  // easu_lane_column
 
 namespace fsr1 {
 
@@ -59,7 +58,7 @@ __global__ void __launch_bounds__(kThreads) fused_h_kernel(const FusedArgs a) {
     mid[my * kMidW + mx] = px;
   };
 #pragma unroll 1
-  for (int my = wave; my < kMidH; my += 4) easu_to_mid(easu_lane_column(lane), my);  // (lane -> column: see easu_lane_column)
+  for (int my = wave; my < kMidH; my += 4) easu_to_mid(lane, my);
   if (wave == 3)  // the two columns left over (64, 65)
     for (int t2 = lane; t2 < 2 * kMidH; t2 += 64) easu_to_mid(kTileW + (t2 & 1), t2 >> 1);
   __syncthreads();

@@ -62,11 +62,10 @@ __global__ void __launch_bounds__(kThreads) fused_kernel(const FusedArgs a) {
   //      RCAS follows: FSR_Filter.cpp:107).  A lane owns apron column `lane` (its x position math is done once),
   //      the waves share the kMidH rows; the two columns left over (64, 65) are one extra partial pass. ----
   const int lane = tid & 63, wave = tid >> 6;
-  auto easu_to_mid = [&](int mx, int my, float ppx, int lxf, bool x_ok) {
+  auto easu_to_mid = [&](int mx, int my, float ppx, int lxf, bool x_ok, float4_t t0, float4_t t1) {
     const int oy = oy0 - 1 + my;
     texel_t px = Pixel<FMT>::zero();
     if (x_ok && oy >= ylo && oy <= yhi) {
-      const float4_t t0 = rowt[2 * my], t1 = rowt[2 * my + 1];
       const EasuRowTerms yt = {t0.x, 1.0f - t0.x, t0.y, t0.z, t1.x, t1.y, t1.z, t1.w, 0.0f - t0.x};
       const int f_idx = (int)as_u32(t0.w) + lxf;
       EasuBounds m;
@@ -88,8 +87,15 @@ __global__ void __launch_bounds__(kThreads) fused_kernel(const FusedArgs a) {
     int lxf;
     const int mx = easu_lane_column(lane);  // sixteen consecutive columns per LDS lane group: no bank conflicts on the window reads
     const bool x_ok = x_position(mx, ppx, lxf);
+    float4_t n0 = rowt[2 * wave], n1 = rowt[2 * wave + 1];  // row terms one row ahead of the window reads that depend on them
 #pragma unroll 1
-    for (int my = wave; my < kMidH; my += 4) easu_to_mid(mx, my, ppx, lxf, x_ok);
+    for (int my = wave; my < kMidH; my += 4) {
+      const float4_t t0 = n0, t1 = n1;
+      const int nmy = min(my + 4, kMidH - 1);
+      n0 = rowt[2 * nmy];
+      n1 = rowt[2 * nmy + 1];
+      easu_to_mid(mx, my, ppx, lxf, x_ok, t0, t1);
+    }
   }
   // leftover columns: 2 x kMidH pixels, given to the last wave (it has the fewest rows above when kMidH % 4 == 2)
   if (wave == 3) {
@@ -98,7 +104,7 @@ __global__ void __launch_bounds__(kThreads) fused_kernel(const FusedArgs a) {
       int lxf;
       const int mx = kTileW + (t & 1), my = t >> 1;
       const bool x_ok = x_position(mx, ppx, lxf);
-      easu_to_mid(mx, my, ppx, lxf, x_ok);
+      easu_to_mid(mx, my, ppx, lxf, x_ok, rowt[2 * my], rowt[2 * my + 1]);
     }
   }
   __syncthreads();
