@@ -444,6 +444,28 @@ def main():
                                             "note": "FsrEasuH + FsrRcasH (parity class H: bit-exact vs the reference's packed-fp16 path; "
                                                     "v_pk_*_f16 issue at half rate on MI355X, DESIGN.md 3.4)"}
 
+        if args.workload == "1080p_to_4k" and args.storage == "rgba16f" and args.math == "f" and not args.no_fast_paths:
+            # BASELINE configs[2]'s shape on the same box and K steps (one 2560x1440 -> 3840x2160 frame per step, "Quality"
+            # 1.5x): the ratios without a quad form run the generic kernels, which the exact-2x headline never touches
+            q_in = [torch.roll(torch.from_numpy(fsr.frames.synthetic_frame(2560, 1440, k=3 + 16 * rank)).to(device), shifts=(3 * s, 5 * s), dims=(0, 1)).contiguous().unsqueeze(0)
+                    for s in range(ring)]
+            q_con = fsr.FsrEasuCon(2560, 1440, 2560, 1440, out_w, out_h)
+
+            def q_step(i):
+                fsr.easu(q_in[i % ring], mid, con=q_con, flags=math_flags)
+                fsr.rcas(mid, dsts[i % ring], con=rcas_con, flags=math_flags)
+            for i in range(min(args.warmup, 50)):
+                q_step(i)
+            fence()
+            t0 = time.perf_counter()
+            for i in range(args.steps):
+                q_step(i)
+            tq = reduce_counters(args.steps, args.steps * out_w * out_h, close() - t0, coll_device)
+            also["quality_1440p_to_4k_two_pass"] = {"value": round(tq["pixels"] / tq["seconds"] / 1e6, 1), "unit": "Mpix/s",
+                                                    "ms_per_step": round(tq["seconds"] * 1e3 / args.steps, 5),
+                                                    "note": "2560x1440 -> 3840x2160 (1.5x, BASELINE configs[2]'s shape), EASU + RCAS as two dispatches, generic kernels"}
+            del q_in
+
     # ---- per-kernel durations with HIP events on the launch stream (C-ABI stopwatch) ----
     timer = fsr.Timer()
 
