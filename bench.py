@@ -45,6 +45,8 @@ WORKLOADS = {
     "540p_to_1080p": (960, 540, 1920, 1080, 1),          # configs[0] shape
     "270p_to_540p": (480, 270, 960, 540, 1),             # a launch-bound size (see --graph)
     "720p_to_1440p": (1280, 720, 2560, 1440, 1),         # the reference's other published target (PDF p.9: 1440p output)
+    "720p_to_1080p": (1280, 720, 1920, 1080, 1),         # 1.5x at a launch-bound size (`auto` takes the fused launch below 3 Mpixel)
+    "831p_to_1080p": (1477, 831, 1920, 1080, 1),         # 1.3x at the same size
     "1440p_to_4k": (2560, 1440, 3840, 2160, 1),          # 1.5x "Quality", one frame
     "1270p_to_4k": (2259, 1270, 3840, 2160, 1),          # 1.7x "Balanced" (PDF p.10 true-ratio shape)
     "1662p_to_4k": (2954, 1662, 3840, 2160, 1),          # 1.3x "Ultra Quality"

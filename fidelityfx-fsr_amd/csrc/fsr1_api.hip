@@ -471,10 +471,10 @@ static int fused_dispatch_impl(const fsr1_image* in, const fsr1_image* out, cons
   a.tiles_x = (out->width + kTileW - 1) / kTileW;
   a.tiles_y = (out->height + kFusedTileH - 1) / kFusedTileH;
   a.frames = out->frames;
-  // Exact 2x (con0 = {1/2, 1/2, -1/4, -1/4}), plain F arithmetic, a whole image: the variant whose lanes own 2x2 quads
+  // Exact 2x (con0 = {1/2, 1/2, -1/4, -1/4}), plain F arithmetic, a whole image or a band from an even row: the variant whose lanes own 2x2 quads
   // of the apron tile (fsr1_fused_s2.hip); its tiles are 62 pixels wide and 2 QH - 2 tall.
   const bool s2 = easu_con[0] == 0x3f000000u && easu_con[1] == 0x3f000000u && easu_con[2] == 0xbe800000u && easu_con[3] == 0xbe800000u &&
-                  !(flags & FSR1_FLAG_NO_FAST_PATHS) && !packed && !a.color.stages && !origin_y && !rows_above && !rows_below &&
+                  !(flags & FSR1_FLAG_NO_FAST_PATHS) && !packed && !a.color.stages && !(origin_y & 1) &&
                   fused_s2_lds_bytes(in->format, fused_s2_quad_rows()) <= 160 * 1024;
   if (s2) fused_s2_geometry(out->width, out->height, fused_s2_quad_rows(), &a.tiles_x, &a.tiles_y);
   if ((rc = check_grid("fused", a.tiles_x, a.tiles_y, a.frames))) return rc;

@@ -10,7 +10,8 @@
 // Phase 4 (RCAS) has lane L own apron column L: lanes 1 .. 62 are the tile's output columns and lanes 0 / 63 the apron
 // columns themselves, so both horizontal neighbours of every output pixel arrive by DPP wave shifts and nothing but the
 // lane's own column is read from LDS.  Same per-pixel functions on the same values as the generic kernel and as the two
-// dispatches: bit-identical output (tests/test_gpu_parity.py, test_gpu_fullframe.py).
+// dispatches: bit-identical output (tests/test_gpu_parity.py, test_gpu_fullframe.py).  Row bands with an even origin
+// (tests/test_gpu_bands.py) run this kernel too.
 #include "fsr1_device.h"
 #include "fsr1_device_easu.hpp"
 #include "fsr1_device_rcas.hpp"
@@ -47,8 +48,12 @@ __global__ void __launch_bounds__(kThreads) fused_s2_kernel(const FusedArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
   l.fw = kFs2FpW;
-  easu_stage_footprint<FMT, false, EXACT, kFs2FpW, kFpH>(l, a.in, a.in.base + (long long)frame * a.in.frame_stride, 31 * tx - 2, (QH - 1) * ty - 2,
-                                                         kFs2FpW, kFpH, tid);
+  // (a band of a larger output image, fsr1_easu_rcas_fused_dispatch_band: output row 0 is row a.origin_y — even, the host
+  //  checks — of the image the constants describe, and the rows just above / below the band exist there when rows_above /
+  //  rows_below say so: the apron computes them instead of taking them as outside the image)
+  easu_stage_footprint<FMT, false, EXACT, kFs2FpW, kFpH>(l, a.in, a.in.base + (long long)frame * a.in.frame_stride, 31 * tx - 2,
+                                                         (QH - 1) * ty - 2 + (a.origin_y >> 1), kFs2FpW, kFpH, tid);
+  const int ylo = -a.rows_above, yhi = H - 1 + a.rows_below;
 
   // ---- phase 3: EASU on the apron tile, a quad per lane and iteration, rounded to the storage format (EASU runs with
   //      Sample.x = 0 when RCAS follows: FSR_Filter.cpp:107); pixels outside the image are 0 (FSR_Pass.hlsl:45,61) ----
@@ -57,7 +62,7 @@ __global__ void __launch_bounds__(kThreads) fused_s2_kernel(const FusedArgs a) {
   for (int k = 0; k < QH / 8; ++k) {
     const int qx = lane & 31, qy = 8 * k + 2 * wave + (lane >> 5);
     const int oxa = ax0 + 2 * qx, oya = ay0 + 2 * qy;
-    const bool xin0 = oxa >= 0 && oxa < W, xin1 = oxa + 1 < W, yin0 = oya >= 0 && oya < H, yin1 = oya + 1 < H;
+    const bool xin0 = oxa >= 0 && oxa < W, xin1 = oxa + 1 < W, yin0 = oya >= ylo && oya <= yhi, yin1 = oya + 1 <= yhi;
     const int f_idx = (qy + 1) * kFs2FpW + (qx + 1);
     texel_t* const m0 = mid + (2 * qy) * kFs2MidW + 2 * qx;
     typedef typename TexelPair<FMT>::T pair_t;
