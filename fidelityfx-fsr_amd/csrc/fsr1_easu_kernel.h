@@ -130,6 +130,7 @@ __global__ void __launch_bounds__(kThreads) easu_kernel(const EasuArgs a) {
   for (int r = 0; r < kTileH / 4; ++r) {
     const int row = wave * (kTileH / 4) + r, oy = oy0 + row;
     if (oy >= a.out.height) break;
+#ifndef FSR1_EASU_NO_ROWT
     const float4_t t0 = n0, t1 = n1;
     {
       const int nrow = min(row + 1, kTileH - 1);
@@ -138,6 +139,14 @@ __global__ void __launch_bounds__(kThreads) easu_kernel(const EasuArgs a) {
     }
     const EasuRowTerms yt = {t0.x, 1.0f - t0.x, t0.y, t0.z, t1.x, t1.y, t1.z, t1.w, 0.0f - t0.x};
     const int f_idx = (int)as_u32(t0.w) + lx;
+#else  // tuning experiment: the row terms evaluated per pixel
+    float ppy = (float)(oy + a.origin_y) * c0y + c0w;
+    const float fpy = floorf(ppy);
+    ppy -= fpy;
+    const EasuRowTerms yt = easu_row_terms(ppy);
+    const int f_idx = ((int)fpy - fy0) * row_stride + lx;
+    (void)n0; (void)n1;
+#endif
     EasuBounds m;
     const rgbf_t p = easu_pixel_with_bounds<EXACT>(l, f_idx, ppx, yt, m);
     texel_t* const dst = reinterpret_cast<texel_t*>(out_col + (long long)oy * a.out.pitch);
