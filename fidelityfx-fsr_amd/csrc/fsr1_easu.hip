@@ -33,7 +33,7 @@ namespace fsr1 {
 // Bytes of dynamic LDS the kernel needs for a footprint capacity of fp_w x fp_h texels.
 size_t easu_lds_bytes(int fmt, int fp_w, int fp_h) {
   (void)fmt;
-  return easu_lds_region_bytes((size_t)fp_w * fp_h) + (size_t)kTileH * 2 * sizeof(float4_t);  // footprint + the row-terms table of the generic kernel
+  return easu_lds_region_bytes((size_t)fp_w * fp_h);
 }
 
 // Compile-time LDS pitches of the generic kernel's row-interleaved layout (default arithmetic, plain pass).  A tile's footprint

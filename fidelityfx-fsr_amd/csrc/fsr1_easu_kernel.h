@@ -94,18 +94,6 @@ __global__ void __launch_bounds__(kThreads) easu_kernel(const EasuArgs a) {
   const int fh = min((int)floorf((float)(oyl + a.origin_y) * c0y + c0w) + 2 - fy0 + 1, a.fp_h);
   if (!PITCH) l.fw = fw;
   const int row_stride = PITCH ? 2 * PITCH : fw;  // LDS records between footprint rows
-  // The row-only terms of the filter (ffx_fsr1.h:324-326 for y, the tap-row offsets and their squares, the footprint row of
-  // texel 'f') are the same for the 64 pixels of an output row: lanes 0 .. kTileH-1 evaluate them once per tile — the very
-  // operations every pixel would otherwise run — and park them behind the footprint; the staging barriers publish them.
-  float4_t* const rowt = reinterpret_cast<float4_t*>(smem + easu_lds_region_bytes((size_t)(PITCH ? PITCH : a.fp_w) * a.fp_h));  // [kTileH][2]
-  if (tid < kTileH) {
-    float ppy = (float)(oy0 + tid + a.origin_y) * c0y + c0w;
-    const float fpy = floorf(ppy);
-    ppy -= fpy;
-    const EasuRowTerms y = easu_row_terms(ppy);
-    rowt[2 * tid + 0] = float4_t{y.ppy, y.oym, y.oy2, as_f32((uint32_t)(((int)fpy - fy0) * row_stride))};
-    rowt[2 * tid + 1] = float4_t{y.sqm, y.sq0, y.sq1, y.sq2};
-  }
   easu_stage_footprint<FMT, COLOR, EXACT, 0, 0, kThreads, PITCH>(l, a.in, in_frame, fx0, fy0, fw, fh, tid, &a.color);
 
   // ---- phase 3: output pixels; a lane owns a column, a wave kTileH / 4 rows.  Which column: easu_lane_column — sixteen
@@ -123,30 +111,15 @@ __global__ void __launch_bounds__(kThreads) easu_kernel(const EasuArgs a) {
   const bool hdr = COLOR ? (a.flags & FSR1_FLAG_HDR_SQUARE) != 0 : HDR;
   const bool stream = (a.flags & FSR1_FLAG_OUTPUT_STREAMING) != 0;
 
-  // the row terms are read one row ahead: the window's address depends on them, and two LDS round trips in a row would
-  // otherwise open every pixel
-  float4_t n0 = rowt[2 * (wave * (kTileH / 4))], n1 = rowt[2 * (wave * (kTileH / 4)) + 1];
 #pragma unroll 1
   for (int r = 0; r < kTileH / 4; ++r) {
-    const int row = wave * (kTileH / 4) + r, oy = oy0 + row;
+    const int oy = oy0 + wave * (kTileH / 4) + r;
     if (oy >= a.out.height) break;
-#ifndef FSR1_EASU_NO_ROWT
-    const float4_t t0 = n0, t1 = n1;
-    {
-      const int nrow = min(row + 1, kTileH - 1);
-      n0 = rowt[2 * nrow];
-      n1 = rowt[2 * nrow + 1];
-    }
-    const EasuRowTerms yt = {t0.x, 1.0f - t0.x, t0.y, t0.z, t1.x, t1.y, t1.z, t1.w, 0.0f - t0.x};
-    const int f_idx = (int)as_u32(t0.w) + lx;
-#else  // tuning experiment: the row terms evaluated per pixel
-    float ppy = (float)(oy + a.origin_y) * c0y + c0w;
+    float ppy = (float)(oy + a.origin_y) * c0y + c0w;  // :324-326
     const float fpy = floorf(ppy);
     ppy -= fpy;
     const EasuRowTerms yt = easu_row_terms(ppy);
     const int f_idx = ((int)fpy - fy0) * row_stride + lx;
-    (void)n0; (void)n1;
-#endif
     EasuBounds m;
     const rgbf_t p = easu_pixel_with_bounds<EXACT>(l, f_idx, ppx, yt, m);
     texel_t* const dst = reinterpret_cast<texel_t*>(out_col + (long long)oy * a.out.pitch);

@@ -16,11 +16,7 @@ namespace fsr1 {
 
 size_t fused_lds_bytes(int fmt, int fp_w, int fp_h) {
   const size_t texel = fmt == FSR1_FORMAT_RGBA32F ? 16 : (fmt == FSR1_FORMAT_RGBA16F ? 8 : 4);
-#ifdef FSR1_FUSED_ROWT  // tuning experiment: + the row-terms table
-  return easu_lds_region_bytes((size_t)fp_w * fp_h) + (((size_t)kMidW * kMidH * texel + 15) & ~(size_t)15) + (size_t)kMidH * 2 * sizeof(float4_t);
-#else
   return easu_lds_region_bytes((size_t)fp_w * fp_h) + (size_t)kMidW * kMidH * texel;  // footprint + the intermediate tile
-#endif
 }
 
 hipError_t fused_launch(const FusedArgs& a, int fmt, bool exact, hipStream_t stream) {

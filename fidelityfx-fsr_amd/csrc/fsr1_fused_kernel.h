@@ -46,21 +46,6 @@ __global__ void __launch_bounds__(kThreads) fused_kernel(const FusedArgs a) {
   l.fw = fw;
 
   const int tid = threadIdx.x;
-  // Row-only terms of the EASU filter once per apron row, as in easu_kernel?  Measured and NOT taken here (FSR1_FUSED_ROWT builds
-  // it): this kernel is short of LDS cycles and of resident waves (three workgroups per CU at 1.3x), and two more LDS reads in
-  // front of every window cost more than the fifteen VALU instructions they replace — 1662p -> 4K 94.5 -> 108.8 us with the
-  // table alone, profiles/ab_r03/r3c6_fused_generic_attribution_ab.log.
-#ifdef FSR1_FUSED_ROWT
-  float4_t* const rowt = reinterpret_cast<float4_t*>(smem + easu_lds_region_bytes(cap) + (((size_t)kMidW * kMidH * sizeof(texel_t) + 15) & ~(size_t)15));  // [kMidH][2]
-  if (tid < kMidH) {
-    float ppy = (float)(oy0 - 1 + tid + yorg) * c0y + c0w;  // :324-326
-    const float fpy = floorf(ppy);
-    ppy -= fpy;
-    const EasuRowTerms y = easu_row_terms(ppy);
-    rowt[2 * tid + 0] = float4_t{y.ppy, y.oym, y.oy2, as_f32((uint32_t)(((int)fpy - fy0) * fw))};
-    rowt[2 * tid + 1] = float4_t{y.sqm, y.sq0, y.sq1, y.sq2};
-  }
-#endif
   easu_stage_footprint<FMT, COLOR, EXACT>(l, a.in, a.in.base + (long long)frame * a.in.frame_stride, fx0, fy0, fw, fh, tid, &a.color);
 
   // ---- phase 3: EASU on the apron tile -> LDS, in the storage format (EASU runs with Sample.x = 0 when
@@ -71,24 +56,12 @@ __global__ void __launch_bounds__(kThreads) fused_kernel(const FusedArgs a) {
     const int oy = oy0 - 1 + my;
     texel_t px = Pixel<FMT>::zero();
     if (x_ok && oy >= ylo && oy <= yhi) {
-#ifdef FSR1_FUSED_ROWT
-      const float4_t t0 = rowt[2 * my], t1 = rowt[2 * my + 1];
-      const EasuRowTerms yt = {t0.x, 1.0f - t0.x, t0.y, t0.z, t1.x, t1.y, t1.z, t1.w, 0.0f - t0.x};
-      const int f_idx = (int)as_u32(t0.w) + lxf;
-#else
       float ppy = (float)(oy + yorg) * c0y + c0w;  // :324-326
       const float fpy = floorf(ppy);
       ppy -= fpy;
-      const EasuRowTerms yt = easu_row_terms(ppy);
       const int f_idx = ((int)fpy - fy0) * fw + lxf;
-#endif
-#ifdef FSR1_FUSED_NO_TAPBOUNDS  // tuning experiment
-      const rgbf_t p = easu_pixel<EXACT>(l, f_idx, ppx, yt);
-      const EasuBounds m = easu_bounds(l, f_idx);
-#else
-      EasuBounds m;
-      const rgbf_t p = easu_pixel_with_bounds<EXACT>(l, f_idx, ppx, yt, m);
-#endif
+      EasuBounds m;  // taken of the taps as they arrive: no second read of f g j k
+      const rgbf_t p = easu_pixel_with_bounds<EXACT>(l, f_idx, ppx, easu_row_terms(ppy), m);
       px = easu_resolve<FMT, EXACT>(m, p, false);
     }
     mid[my * kMidW + mx] = px;
@@ -104,11 +77,7 @@ __global__ void __launch_bounds__(kThreads) fused_kernel(const FusedArgs a) {
   {
     float ppx;
     int lxf;
-#ifdef FSR1_FUSED_NO_PERM  // tuning experiment
-    const int mx = lane;
-#else
     const int mx = easu_lane_column(lane);  // sixteen consecutive columns per LDS lane group: no bank conflicts on the window reads
-#endif
     const bool x_ok = x_position(mx, ppx, lxf);
 #pragma unroll 1
     for (int my = wave; my < kMidH; my += 4) easu_to_mid(mx, my, ppx, lxf, x_ok);

@@ -151,16 +151,15 @@ struct rgbf_t { float r, g, b; };
 // the four analyses through `ana(k)`, k = 0..3 for f, g, j, k (easu_analysis).  Returns aC * rcp(aW).  Everything up to
 // the `dirR < 1/32768` decision is evaluated in the reference's exact operation order: that decision (and floor() in
 // the caller) are the filter's only discontinuities.
-// The terms of the filter that depend on the sub-texel ROW position only.  Every pixel of an output row shares them, so a
-// tiled kernel may evaluate them once per row (easu_kernel: sixteen lanes, once per tile, parked in LDS) instead of once
-// per pixel; easu_filter(..., ppx, ppy) evaluates them in place.  Same operations on the same values either way.
+// The terms of the filter that depend on the sub-texel ROW position only, grouped so that a caller whose pixels share a row
+// may evaluate them once (easu_filter(..., ppx, ppy) evaluates them in place).  Parking them in LDS once per tile row was
+// measured in round 3 and not kept: no gain in the EASU kernel, -2 % / +15 % (1.5x / 1.3x) in the generic fused kernel
+// (profiles/ab_r03/r3c7_row_terms_table_ab.log).
 struct EasuRowTerms {
   float ppy, omy, oym, oy2;    // sub-texel position (:324-326), 1 - ppy, and the tap-row offsets -1 - ppy, 2 - ppy
   float sqm, sq0, sq1, sq2;    // squares of the four tap-row offsets oym, oy0 = 0 - ppy, oy1 = omy, oy2
   float oy0;
 };
-// (kernels park {ppy, oym, oy2, footprint row} and the four squares — two 16-byte records per row — and re-derive omy and
-// oy0 from ppy per pixel: one subtraction each, the operations easu_row_terms runs)
 __device__ __forceinline__ EasuRowTerms easu_row_terms(float ppy) {
   EasuRowTerms y;
   y.ppy = ppy; y.omy = 1.0f - ppy; y.oym = -1.0f - ppy; y.oy0 = 0.0f - ppy; y.oy2 = 2.0f - ppy;
