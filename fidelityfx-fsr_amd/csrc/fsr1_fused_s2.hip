@@ -66,7 +66,17 @@ __global__ void __launch_bounds__(kThreads) fused_s2_kernel(const FusedArgs a) {
     const int f_idx = (qy + 1) * kFs2FpW + (qx + 1);
     texel_t* const m0 = mid + (2 * qy) * kFs2MidW + 2 * qx;
     typedef typename TexelPair<FMT>::T pair_t;
-    if (xin0 && xin1 && yin0 && yin1) {  // every quad but those on the image's border
+    if (!EXACT && xin0 && xin1 && yin0 && yin1) {  // default arithmetic: analyses once per quad, bounds of the first pixel's taps (see easu_kernel)
+      const float4_t A[4] = {l.ana[f_idx], l.ana[f_idx + 1], l.ana[f_idx + kFs2FpW], l.ana[f_idx + kFs2FpW + 1]};
+      EasuBounds m;
+      const rgbf_t q00 = easu_quad_pixel<EXACT, true>(l, f_idx, 0.25f, 0.25f, A, m);
+      const texel_t p00 = easu_resolve<FMT, EXACT>(m, q00, false);
+      const texel_t p10 = easu_resolve<FMT, EXACT>(m, easu_quad_pixel<EXACT, false>(l, f_idx, 0.75f, 0.25f, A, m), false);
+      const texel_t p01 = easu_resolve<FMT, EXACT>(m, easu_quad_pixel<EXACT, false>(l, f_idx, 0.25f, 0.75f, A, m), false);
+      const texel_t p11 = easu_resolve<FMT, EXACT>(m, easu_quad_pixel<EXACT, false>(l, f_idx, 0.75f, 0.75f, A, m), false);
+      *reinterpret_cast<pair_t*>(m0) = TexelPair<FMT>::make(p00, p10);
+      *reinterpret_cast<pair_t*>(m0 + kFs2MidW) = TexelPair<FMT>::make(p01, p11);
+    } else if (xin0 && xin1 && yin0 && yin1) {  // every quad but those on the image's border
       const EasuBounds m = easu_bounds(l, f_idx);
       const texel_t p00 = easu_resolve<FMT, EXACT>(m, easu_pixel<EXACT>(l, f_idx, 0.25f, 0.25f), false);
       const texel_t p10 = easu_resolve<FMT, EXACT>(m, easu_pixel<EXACT>(l, f_idx, 0.75f, 0.25f), false);

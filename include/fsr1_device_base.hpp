@@ -88,7 +88,12 @@ template <int FMT> struct Pixel;  // FMT = fsr1_format
 template <> struct Pixel<FSR1_FORMAT_RGBA16F> {
   typedef half4_t T;
   static __device__ __forceinline__ float4_t load(const T& p) { return float4_t{(float)p.x, (float)p.y, (float)p.z, (float)p.w}; }
-  static __device__ __forceinline__ T store(float r, float g, float b, float a) { return T{to_half(r), to_half(g), to_half(b), to_half(a)}; }
+  // two v_cvt_pk_f16_f32 (RTNE, two values per instruction): written as vector conversions, because from the element-wise
+  // form the compiler builds three v_cvt_f16_f32 and two v_perm_b32 once the values have been through pinned()
+  static __device__ __forceinline__ T store(float r, float g, float b, float a) {
+    const half2_t rg = __builtin_convertvector(float2_t{r, g}, half2_t), ba = __builtin_convertvector(float2_t{b, a}, half2_t);
+    return T{rg.x, rg.y, ba.x, ba.y};
+  }
   static __device__ __forceinline__ T zero() { return T{(half_t)0, (half_t)0, (half_t)0, (half_t)0}; }
 };
 // UNORM decode: code / N correctly rounded (N = 255, 1023, 3) without a division: the product by the rounded

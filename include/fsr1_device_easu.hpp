@@ -355,6 +355,30 @@ __device__ __forceinline__ rgbf_t easu_pixel_with_bounds(const EasuLds& l, int f
   return p;
 }
 
+// The exact-2x quad form: the four pixels of a quad share the texel 'f', hence the four analyses and the dering bounds.  `A` holds
+// the analyses of f g j k, loaded once per quad by the caller; WITH_BOUNDS additionally takes the bounds of the tap values
+// (one pixel of the quad does that, the others reuse them).
+template <bool EXACT, bool WITH_BOUNDS>
+__device__ __forceinline__ rgbf_t easu_quad_pixel(const EasuLds& l, int f_idx, float ppx, float ppy, const float4_t (&A)[4], EasuBounds& m) {
+  const int fw = l.fw;
+  const float4_t* const w0 = l.tex + (f_idx - fw - 1);
+  float4_t cf = {}, cg = {}, cj = {}, ck = {};
+  const rgbf_t p = easu_filter<EXACT>(
+      [&](int dx, int dy) {
+        const float4_t v = w0[(dy + 1) * fw + (dx + 1)];
+        if (WITH_BOUNDS) {
+          if (dy == 0 && dx == 0) cf = v;
+          else if (dy == 0 && dx == 1) cg = v;
+          else if (dy == 1 && dx == 0) cj = v;
+          else if (dy == 1 && dx == 1) ck = v;
+        }
+        return v;
+      },
+      [&](int k) { return A[k]; }, ppx, ppy);
+  if (WITH_BOUNDS) m = easu_bounds(cf, cg, cj, ck);
+  return p;
+}
+
 // Dering clamp in binary32 (:437 `min(max4, max(min4, pix))`) + optional `c *= c` (FSR_Pass.hlsl:78-79): the filter's
 // result before the store conversion.  Clamping before or after the store's rounding gives the same stored value: rounding
 // is monotone and the bounds are values of the storage format.  EXACT keeps the reference's two operations; the default
