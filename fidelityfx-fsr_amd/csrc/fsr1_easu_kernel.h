@@ -23,7 +23,10 @@ int easu_lds_pitch(int fp_w, bool exact, bool color);
 // PITCH (generic variant only): 0 = dense LDS arrays of the tile's own footprint width; P = the row-interleaved layout with
 // the compile-time pitch P >= a.fp_w (easu_lds_carve_pitched): no LDS address arithmetic per tap row.
 template <int FMT, bool EXACT, bool COLOR = false, int FOUT = FMT, bool S2 = false, bool HDR = false, int PITCH = 0>
-__global__ void __launch_bounds__(kThreads) easu_kernel(const EasuArgs a) {
+// amdgpu_waves_per_eu(7, 8): at least seven waves per SIMD, i.e. at most 72 VGPRs.  Only the exact-2x default-arithmetic
+// variant is affected — its row-pair form would take 85 (five waves: 43.7 us) where 68 cost it nothing (41.6 us); every other
+// variant needs fewer than 64 anyway.
+__global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(7, 8))) easu_kernel(const EasuArgs a) {
   typedef typename Pixel<FOUT>::T texel_t;
   constexpr bool kS2 = S2 && kTileH % 16 == 0;  // (other tile heights are tuning builds: the host never selects S2 for them)
   constexpr int kS2W = kTileW / 2 + 3, kS2H = kTileH / 2 + 3;  // footprint of every exact-2x tile
@@ -60,19 +63,19 @@ __global__ void __launch_bounds__(kThreads) easu_kernel(const EasuArgs a) {
       const int f_idx = (qy + 1) * kS2W + (qx + 1);
       char* const o0 = a.out.base + (long long)frame * a.out.frame_stride + (long long)oya * a.out.pitch + (long long)oxa * (long long)sizeof(texel_t);
       if constexpr (!EXACT) {
-        // default arithmetic: the quad's four analyses are loaded once and its dering bounds taken of the first pixel's taps —
-        // 52 instead of 60 LDS reads per quad for 9 more VGPRs (57): -2 % (profiles/ab_r03/r3c8_s2_shared_analyses_ab.log).  (The
-        // EXACT variant would need 103 VGPRs for it and keeps the per-pixel loads.)
+        // default arithmetic: a quad is filtered as two ROW PAIRS — the two pixels of a row share the 12-tap window, so every
+        // texel is read from LDS once per row and used for both (28 instead of 60 ds_read_b128 per quad: the four analyses once
+        // per quad, the dering bounds taken of the first row's tap values).  Same statements per pixel as easu_pixel: bit-identical.
+        // LDS cycles matter well before the LDS is "the" limiter: 43.7 -> 41.6 us at 1080p -> 4K.  (EXACT keeps
+        // the per-pixel form: its pair would need more than a hundred VGPRs.)
         if (xin0 && xin1 && yin0 && yin1) {
           const float4_t A[4] = {l.ana[f_idx], l.ana[f_idx + 1], l.ana[f_idx + kS2W], l.ana[f_idx + kS2W + 1]};
           EasuBounds m;
-          const rgbf_t q00 = easu_quad_pixel<EXACT, true>(l, f_idx, 0.25f, 0.25f, A, m);
-          const texel_t p00 = easu_resolve<FMT, EXACT>(m, q00, hdr);
-          const texel_t p10 = easu_resolve<FMT, EXACT>(m, easu_quad_pixel<EXACT, false>(l, f_idx, 0.75f, 0.25f, A, m), hdr);
-          const texel_t p01 = easu_resolve<FMT, EXACT>(m, easu_quad_pixel<EXACT, false>(l, f_idx, 0.25f, 0.75f, A, m), hdr);
-          const texel_t p11 = easu_resolve<FMT, EXACT>(m, easu_quad_pixel<EXACT, false>(l, f_idx, 0.75f, 0.75f, A, m), hdr);
-          store_out<sizeof(texel_t)>(o0, TexelPair<FOUT>::make(p00, p10), stream);
-          store_out<sizeof(texel_t)>(o0 + a.out.pitch, TexelPair<FOUT>::make(p01, p11), stream);
+          rgbf_t q00, q10, q01, q11;
+          easu_quad_row<true>(l, f_idx, 0.25f, A, m, q00, q10);
+          store_out<sizeof(texel_t)>(o0, TexelPair<FOUT>::make(easu_resolve<FMT, EXACT>(m, q00, hdr), easu_resolve<FMT, EXACT>(m, q10, hdr)), stream);
+          easu_quad_row<false>(l, f_idx, 0.75f, A, m, q01, q11);
+          store_out<sizeof(texel_t)>(o0 + a.out.pitch, TexelPair<FOUT>::make(easu_resolve<FMT, EXACT>(m, q01, hdr), easu_resolve<FMT, EXACT>(m, q11, hdr)), stream);
           continue;
         }
       }

@@ -31,7 +31,7 @@ void fused_s2_geometry(int width, int height, int qh, int* tiles_x, int* tiles_y
 }
 
 template <int FMT, bool EXACT, int QH>
-__global__ void __launch_bounds__(kThreads) fused_s2_kernel(const FusedArgs a) {
+__global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(7, 8))) fused_s2_kernel(const FusedArgs a) {  // (<= 72 VGPRs: 7 workgroups per CU is what its LDS admits)
   typedef typename Pixel<FMT>::T texel_t;
   static_assert(QH % 8 == 0 && kThreads == 256, "32 x QH quads over 256 lanes");
   constexpr int kFpH = QH + 3, kOutH = 2 * QH - 2;  // (the apron tile is 2 QH rows tall)
@@ -66,16 +66,14 @@ __global__ void __launch_bounds__(kThreads) fused_s2_kernel(const FusedArgs a) {
     const int f_idx = (qy + 1) * kFs2FpW + (qx + 1);
     texel_t* const m0 = mid + (2 * qy) * kFs2MidW + 2 * qx;
     typedef typename TexelPair<FMT>::T pair_t;
-    if (!EXACT && xin0 && xin1 && yin0 && yin1) {  // default arithmetic: analyses once per quad, bounds of the first pixel's taps (see easu_kernel)
+    if (!EXACT && xin0 && xin1 && yin0 && yin1) {  // default arithmetic: two row pairs, every texel read once per row (see easu_kernel)
       const float4_t A[4] = {l.ana[f_idx], l.ana[f_idx + 1], l.ana[f_idx + kFs2FpW], l.ana[f_idx + kFs2FpW + 1]};
       EasuBounds m;
-      const rgbf_t q00 = easu_quad_pixel<EXACT, true>(l, f_idx, 0.25f, 0.25f, A, m);
-      const texel_t p00 = easu_resolve<FMT, EXACT>(m, q00, false);
-      const texel_t p10 = easu_resolve<FMT, EXACT>(m, easu_quad_pixel<EXACT, false>(l, f_idx, 0.75f, 0.25f, A, m), false);
-      const texel_t p01 = easu_resolve<FMT, EXACT>(m, easu_quad_pixel<EXACT, false>(l, f_idx, 0.25f, 0.75f, A, m), false);
-      const texel_t p11 = easu_resolve<FMT, EXACT>(m, easu_quad_pixel<EXACT, false>(l, f_idx, 0.75f, 0.75f, A, m), false);
-      *reinterpret_cast<pair_t*>(m0) = TexelPair<FMT>::make(p00, p10);
-      *reinterpret_cast<pair_t*>(m0 + kFs2MidW) = TexelPair<FMT>::make(p01, p11);
+      rgbf_t q00, q10, q01, q11;
+      easu_quad_row<true>(l, f_idx, 0.25f, A, m, q00, q10);
+      *reinterpret_cast<pair_t*>(m0) = TexelPair<FMT>::make(easu_resolve<FMT, EXACT>(m, q00, false), easu_resolve<FMT, EXACT>(m, q10, false));
+      easu_quad_row<false>(l, f_idx, 0.75f, A, m, q01, q11);
+      *reinterpret_cast<pair_t*>(m0 + kFs2MidW) = TexelPair<FMT>::make(easu_resolve<FMT, EXACT>(m, q01, false), easu_resolve<FMT, EXACT>(m, q11, false));
     } else if (xin0 && xin1 && yin0 && yin1) {  // every quad but those on the image's border
       const EasuBounds m = easu_bounds(l, f_idx);
       const texel_t p00 = easu_resolve<FMT, EXACT>(m, easu_pixel<EXACT>(l, f_idx, 0.25f, 0.25f), false);

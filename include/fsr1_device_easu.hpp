@@ -167,6 +167,28 @@ __device__ __forceinline__ EasuRowTerms easu_row_terms(float ppy) {
   return y;
 }
 
+// The default arithmetic's per-pixel tap terms (see the derivation in easu_filter): Q-form of the rotated, scaled offset with
+// the row parts folded in, and the window polynomial's coefficients in u = d2 / clp.
+struct EasuTapTerms { float q00, sm, s0, s1, s2, bm, b0, b1, b2, k1, k2, k3; };
+__device__ __forceinline__ EasuTapTerms easu_tap_terms(float dirx, float diry, float len2x, float len2y, float lob, float clp, const EasuRowTerms& yt) {
+  const float rclp = __builtin_amdgcn_rcpf(clp);
+  const float sx = len2x * len2x * rclp, sy = len2y * len2y * rclp;
+  const float dxx = dirx * dirx, dyy = diry * diry, dxy2 = 2.0f * (dirx * diry);
+  const float q00 = fmaf(dxx, sx, dyy * sy), q11 = fmaf(dyy, sx, dxx * sy), q01 = dxy2 * (sx - sy);
+  EasuTapTerms h;
+  h.q00 = q00;
+  h.sm = q01 * yt.oym; h.s0 = q01 * yt.oy0; h.s1 = q01 * yt.omy; h.s2 = q01 * yt.oy2;
+  h.bm = q11 * yt.sqm; h.b0 = q11 * yt.sq0; h.b1 = q11 * yt.sq1; h.b2 = q11 * yt.sq2;
+  h.k2 = 0.25f * clp * clp; h.k1 = -1.25f * clp; h.k3 = lob * clp;
+  return h;
+}
+__device__ __forceinline__ float easu_tap_weight(const EasuTapTerms& h, float ox, float s, float b) {
+  const float u = sat(fmaf(ox, fmaf(h.q00, ox, s), b));
+  const float base = fmaf(fmaf(h.k2, u, h.k1), u, 1.0f);
+  const float wa = fmaf(h.k3, u, -1.0f);
+  return base * (wa * wa);
+}
+
 template <bool EXACT, class Tex, class Ana>
 __device__ __forceinline__ rgbf_t easu_filter(const Tex& tex, const Ana& ana, float ppx, const EasuRowTerms& yt);
 
@@ -249,19 +271,9 @@ __device__ __forceinline__ rgbf_t easu_filter(const Tex& tex, const Ana& ana, fl
     //   u = min(|v|^2, clp)/clp = sat(off^T Q off),  Q = M^T M / clp  -> the clip is the fma's clamp bit
     //   off^T Q off = ox*(q00*ox + 2*q01*oy) + q11*oy^2      (per-row terms s = 2*q01*oy, b = q11*oy^2)
     //   base = 25/16*(2/5*d2-1)^2 - 9/16 = 1/4*d2^2 - 5/4*d2 + 1,  window = (lob*d2-1)^2,  d2 = clp*u
-    const float rclp = __builtin_amdgcn_rcpf(clp);
-    const float sx = len2x * len2x * rclp, sy = len2y * len2y * rclp;
-    const float dxx = dirx * dirx, dyy = diry * diry, dxy2 = 2.0f * (dirx * diry);
-    const float q00 = fmaf(dxx, sx, dyy * sy), q11 = fmaf(dyy, sx, dxx * sy), q01 = dxy2 * (sx - sy);
-    const float sm = q01 * oym, s0 = q01 * oy0, s1 = q01 * oy1, s2 = q01 * oy2;
-    const float bm = q11 * yt.sqm, b0 = q11 * yt.sq0, b1 = q11 * yt.sq1, b2 = q11 * yt.sq2;
-    const float k2 = 0.25f * clp * clp, k1 = -1.25f * clp, k3 = lob * clp;
-    auto weight = [&](float ox, float s, float b) {
-      const float u = sat(fmaf(ox, fmaf(q00, ox, s), b));
-      const float base = fmaf(fmaf(k2, u, k1), u, 1.0f);
-      const float wa = fmaf(k3, u, -1.0f);
-      return base * (wa * wa);
-    };
+    const EasuTapTerms h = easu_tap_terms(dirx, diry, len2x, len2y, lob, clp, yt);
+    const float sm = h.sm, s0 = h.s0, s1 = h.s1, s2 = h.s2, bm = h.bm, b0 = h.b0, b1 = h.b1, b2 = h.b2;
+    auto weight = [&](float ox, float s, float b) { return easu_tap_weight(h, ox, s, b); };
     auto tap = [&](int dx, int dy, float ox, float s, float b) {
       const float4_t c = tex(dx, dy);
       const float w = weight(ox, s, b);
@@ -377,6 +389,93 @@ __device__ __forceinline__ rgbf_t easu_quad_pixel(const EasuLds& l, int f_idx, f
       [&](int k) { return A[k]; }, ppx, ppy);
   if (WITH_BOUNDS) m = easu_bounds(cf, cg, cj, ck);
   return p;
+}
+
+// Everything of the default arithmetic's filter before the taps, for one pixel: bilinear analysis (:381-386, reference order),
+// normalise and zero test (:389-395), kernel shape (:397-409), tap terms.  The same statements as in easu_filter<false>.
+template <class Ana>
+__device__ __forceinline__ EasuTapTerms easu_pixel_terms(const Ana& ana, float ppx, const EasuRowTerms& yt) {
+  const float ppy = yt.ppy;
+  const float omx = 1.0f - ppx, omy = yt.omy;
+  const float4_t af = ana(0), ag = ana(1), aj = ana(2), ak = ana(3);
+  const float wS = omx * omy, wT = ppx * omy, wU = omx * ppy, wV = ppx * ppy;
+  float dirx = af.x * wS;
+  float diry = af.y * wS;
+  dirx += ag.x * wT; diry += ag.y * wT;
+  dirx += aj.x * wU; diry += aj.y * wU;
+  dirx += ak.x * wV; diry += ak.y * wV;
+  float len = af.z * wS;
+  len = fmaf(ag.z, wT, len);
+  len = fmaf(aj.z, wU, len);
+  len = fmaf(ak.z, wV, len);
+  const float dir2x = dirx * dirx, dir2y = diry * diry;
+  float dirR = dir2x + dir2y;
+  const bool zro = dirR < (1.0f / 32768.0f);
+  dirR = zro ? 1.0f : APrxLoRsqF1(dirR);
+  dirx = zro ? 1.0f : dirx;
+  dirx *= dirR;
+  diry *= dirR;
+  len = len * 0.5f;
+  len *= len;
+  const float stretch = mad<false>(dirx, dirx, diry * diry) * APrxLoRcpF1(fmaxf(fabsf(dirx), fabsf(diry)));
+  const float len2x = mad<false>(stretch - 1.0f, len, 1.0f);
+  const float len2y = mad<false>(-0.5f, len, 1.0f);
+  const float lob = mad<false>((float)((1.0 / 4.0 - 0.04) - 0.5), len, 0.5f);
+  const float clp = APrxLoRcpF1(lob);
+  return easu_tap_terms(dirx, diry, len2x, len2y, lob, clp, yt);
+}
+
+// Two pixels that share their 12-tap window and analyses (the two pixels of a row of an exact-2x quad), filtered together:
+// every texel is read from LDS once and used for both — the default arithmetic's statements, pixel by pixel the same values in the
+// same order as easu_filter<false>, so the results are bit-identical to two single calls.  `tex` is called once per tap.
+template <class Tex, class Ana>
+__device__ __forceinline__ void easu_filter_pair(const Tex& tex, const Ana& ana, float ppxA, float ppxB, float ppy, rgbf_t& outA, rgbf_t& outB) {
+  const EasuRowTerms yt = easu_row_terms(ppy);
+  const EasuTapTerms hA = easu_pixel_terms(ana, ppxA, yt), hB = easu_pixel_terms(ana, ppxB, yt);
+  const float oxA[4] = {-1.0f - ppxA, 0.0f - ppxA, 1.0f - ppxA, 2.0f - ppxA}, oxB[4] = {-1.0f - ppxB, 0.0f - ppxB, 1.0f - ppxB, 2.0f - ppxB};
+  float aR = 0.f, aG = 0.f, aB = 0.f, aW = 0.f, bR = 0.f, bG = 0.f, bB = 0.f, bW = 0.f;
+  auto tap = [&](int dx, int dy, float sA, float tA, float sB, float tB) {
+    const float4_t c = tex(dx, dy);
+    const float wA = easu_tap_weight(hA, oxA[dx + 1], sA, tA), wB = easu_tap_weight(hB, oxB[dx + 1], sB, tB);
+    aR = fmaf(c.x, wA, aR); aG = fmaf(c.y, wA, aG); aB = fmaf(c.z, wA, aB); aW += wA;
+    bR = fmaf(c.x, wB, bR); bG = fmaf(c.y, wB, bG); bB = fmaf(c.z, wB, bB); bW += wB;
+  };
+  {  // the first tap starts the sums
+    const float4_t c = tex(0, -1);
+    aW = easu_tap_weight(hA, oxA[1], hA.sm, hA.bm);
+    bW = easu_tap_weight(hB, oxB[1], hB.sm, hB.bm);
+    aR = c.x * aW; aG = c.y * aW; aB = c.z * aW;
+    bR = c.x * bW; bG = c.y * bW; bB = c.z * bW;
+  }
+  tap(1, -1, hA.sm, hA.bm, hB.sm, hB.bm);
+  tap(-1, 0, hA.s0, hA.b0, hB.s0, hB.b0); tap(0, 0, hA.s0, hA.b0, hB.s0, hB.b0); tap(1, 0, hA.s0, hA.b0, hB.s0, hB.b0); tap(2, 0, hA.s0, hA.b0, hB.s0, hB.b0);
+  tap(-1, 1, hA.s1, hA.b1, hB.s1, hB.b1); tap(0, 1, hA.s1, hA.b1, hB.s1, hB.b1); tap(1, 1, hA.s1, hA.b1, hB.s1, hB.b1); tap(2, 1, hA.s1, hA.b1, hB.s1, hB.b1);
+  tap(0, 2, hA.s2, hA.b2, hB.s2, hB.b2); tap(1, 2, hA.s2, hA.b2, hB.s2, hB.b2);
+  const float rA = __builtin_amdgcn_rcpf(aW), rB = __builtin_amdgcn_rcpf(bW);
+  outA = rgbf_t{pinned(aR * rA), pinned(aG * rA), pinned(aB * rA)};
+  outB = rgbf_t{pinned(bR * rB), pinned(bG * rB), pinned(bB * rB)};
+}
+
+// A row of an exact-2x quad (sub-texel columns 1/4 and 3/4) on a staged footprint; WITH_BOUNDS takes the quad's dering bounds
+// of the tap values on the way.
+template <bool WITH_BOUNDS>
+__device__ __forceinline__ void easu_quad_row(const EasuLds& l, int f_idx, float ppy, const float4_t (&A)[4], EasuBounds& m, rgbf_t& p0, rgbf_t& p1) {
+  const int fw = l.fw;
+  const float4_t* const w0 = l.tex + (f_idx - fw - 1);
+  float4_t cf = {}, cg = {}, cj = {}, ck = {};
+  easu_filter_pair(
+      [&](int dx, int dy) {
+        const float4_t v = w0[(dy + 1) * fw + (dx + 1)];
+        if (WITH_BOUNDS) {
+          if (dy == 0 && dx == 0) cf = v;
+          else if (dy == 0 && dx == 1) cg = v;
+          else if (dy == 1 && dx == 0) cj = v;
+          else if (dy == 1 && dx == 1) ck = v;
+        }
+        return v;
+      },
+      [&](int k) { return A[k]; }, 0.25f, 0.75f, ppy, p0, p1);
+  if (WITH_BOUNDS) m = easu_bounds(cf, cg, cj, ck);
 }
 
 // Dering clamp in binary32 (:437 `min(max4, max(min4, pix))`) + optional `c *= c` (FSR_Pass.hlsl:78-79): the filter's
