@@ -161,9 +161,12 @@ def pmc_traffic(fsr, workload, pipeline, kernel_name, math="f", storage="rgba16f
                 if d.get("source_hash") != now:
                     stale = os.path.relpath(f, ROOT)
                     continue
-                best = (v["hbm_per_launch"]["traffic_bytes"], os.path.relpath(f, ROOT), v.get("pmc_avg_per_launch", {}).get("SQ_INSTS_VALU"))
+                # several variants of one kernel template may be in a trace (EXACT, generic ...): the pipeline's own is the one launched most
+                cand = (v.get("calls", 0), v["hbm_per_launch"]["traffic_bytes"], os.path.relpath(f, ROOT), v.get("pmc_avg_per_launch", {}).get("SQ_INSTS_VALU"))
+                if best is None or cand[0] > best[0]:
+                    best = cand
     if best:
-        return best + (None,)
+        return best[1:] + (None,)
     return (None, None, None, stale)
 
 
@@ -225,6 +228,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cold-rcas", action="store_true",
                     help="skip the extra RCAS launches on an HBM-cold image (profiling runs: keeps rocprofv3's per-kernel average to the pipeline's own launches)")
+    ap.add_argument("--no-also", action="store_true",
+                    help="skip the also_measured pipelines (profiling runs: only the workload's own kernels in the trace)")
     ap.add_argument("--no-fast-paths", action="store_true", help="FSR1_FLAG_NO_FAST_PATHS: generic kernels only (A/B of the exact-2x variants)")
     ap.add_argument("--rotate-intermediary", action="store_true",
                     help="two-pass: rotate the EASU->RCAS intermediary over the ring as well (round 1's method; default: one reused buffer, as the sample has)")
@@ -397,7 +402,7 @@ def main():
     # (tests: fused == two-pass, bit for bit); the default run times it over the same K steps as well and reports it
     # beside the headline, which stays the two-dispatch pipeline BASELINE's metric is quoted on.
     also = None
-    if args.pipeline == "two-pass" and not args.stages and args.math != "h":
+    if args.pipeline == "two-pass" and not args.stages and args.math != "h" and not args.no_also:
         def fused_step(i):
             fsr.easu_rcas_fused(srcs[i % ring], dsts[i % ring], easu_con=easu_con, rcas_con=rcas_con, flags=math_flags)
         for i in range(min(args.warmup, 50)):
