@@ -26,7 +26,7 @@ template <int FMT, bool EXACT, bool COLOR = false, int FOUT = FMT, bool S2 = fal
 // amdgpu_waves_per_eu(7, 8): at least seven waves per SIMD, i.e. at most 72 VGPRs.  Only the exact-2x default-arithmetic
 // variant is affected — its row-pair form would take 85 (five waves: 43.7 us) where 68 cost it nothing (41.6 us); every other
 // variant needs fewer than 64 anyway.
-__global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(S2 ? 7 : 6, 8))) easu_kernel(const EasuArgs a) {
+__global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(7, 8))) easu_kernel(const EasuArgs a) {
   typedef typename Pixel<FOUT>::T texel_t;
   constexpr bool kS2 = S2 && kTileH % 16 == 0;  // (other tile heights are tuning builds: the host never selects S2 for them)
   constexpr int kS2W = kTileW / 2 + 3, kS2H = kTileH / 2 + 3;  // footprint of every exact-2x tile
@@ -131,8 +131,10 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(S
   const bool hdr = COLOR ? (a.flags & FSR1_FLAG_HDR_SQUARE) != 0 : HDR;
   const bool stream = (a.flags & FSR1_FLAG_OUTPUT_STREAMING) != 0;
 
-  // one output pixel: position (:324-326), window, filter + bounds, store
-  auto one_row = [&](int oy) {
+#pragma unroll 1
+  for (int r = 0; r < kTileH / 4; ++r) {
+    const int oy = oy0 + wave * (kTileH / 4) + r;
+    if (oy >= a.out.height) break;
     float ppy = (float)(oy + a.origin_y) * c0y + c0w;  // :324-326
     const float fpy = floorf(ppy);
     ppy -= fpy;
@@ -148,36 +150,6 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(S
     } else {
       store_out<sizeof(texel_t)>(dst, easu_resolve<FMT, EXACT>(m, p, hdr), stream);
     }
-  };
-#pragma unroll 1
-  for (int r = 0; r < kTileH / 4; r += 2) {
-    const int oy = oy0 + wave * (kTileH / 4) + r;
-    if (oy >= a.out.height) break;
-    if constexpr (!EXACT && !COLOR) {
-      // default arithmetic: the lane's two consecutive rows together (easu_filter_vpair) when their windows start 0 or 1 texel
-      // rows apart — always, at ratios >= 1x — so that every texel of the union is read from LDS once: 12 or 16 reads for two
-      // pixels instead of 24.  Wave-uniform choice (a row's pixels share oy).  Same statements per pixel: bit-identical.
-      if (oy + 1 < a.out.height) {
-        float ppyA = (float)(oy + a.origin_y) * c0y + c0w, ppyB = (float)(oy + 1 + a.origin_y) * c0y + c0w;
-        const float fpyA = floorf(ppyA), fpyB = floorf(ppyB);
-        ppyA -= fpyA;
-        ppyB -= fpyB;
-        const int shift = (int)fpyB - (int)fpyA;
-        if (shift == 0 || shift == 1) {
-          const int f_idx = ((int)fpyA - fy0) * row_stride + lx;
-          EasuBounds mA, mB;
-          rgbf_t pA, pB;
-          if (shift == 0) easu_pixel_vpair<0>(l, f_idx, ppx, easu_row_terms(ppyA), easu_row_terms(ppyB), mA, mB, pA, pB);
-          else easu_pixel_vpair<1>(l, f_idx, ppx, easu_row_terms(ppyA), easu_row_terms(ppyB), mA, mB, pA, pB);
-          char* const d0 = out_col + (long long)oy * a.out.pitch;
-          store_out<sizeof(texel_t)>(d0, easu_resolve<FMT, EXACT>(mA, pA, hdr), stream);
-          store_out<sizeof(texel_t)>(d0 + a.out.pitch, easu_resolve<FMT, EXACT>(mB, pB, hdr), stream);
-          continue;
-        }
-      }
-    }
-    one_row(oy);
-    if (oy + 1 < a.out.height) one_row(oy + 1);
   }
 }
 

@@ -456,68 +456,6 @@ __device__ __forceinline__ void easu_filter_pair(const Tex& tex, const Ana& ana,
   outB = rgbf_t{pinned(bR * rB), pinned(bG * rB), pinned(bB * rB)};
 }
 
-// Two vertically adjacent output pixels of one column (same ppx), filtered together.  Their windows start S texel rows apart
-// (S = 0: the same 12 texels; S = 1: shifted by one row — what consecutive output rows are at any ratio >= 1x), so the union is
-// 4 columns x (4 + S) rows and every texel of it is read once and used for whichever of the two pixels taps it: 12 (S = 0) or 16
-// (S = 1) reads for two pixels instead of 24.  Each pixel sees its own taps in the row-major order of easu_filter<false> with
-// the same statements: bit-identical to two single calls.  `tex(c, r)`: column c = -1 .. 2 as in easu_filter, window row
-// r = 0 .. 3 + S counted from pixel A's tap row -1.
-template <int S, class Tex, class AnaA, class AnaB>
-__device__ __forceinline__ void easu_filter_vpair(const Tex& tex, const AnaA& anaA, const AnaB& anaB, float ppx, const EasuRowTerms& ytA,
-                                                  const EasuRowTerms& ytB, rgbf_t& outA, rgbf_t& outB) {
-  static_assert(S == 0 || S == 1, "consecutive output rows of an upscale");
-  const EasuTapTerms hA = easu_pixel_terms(anaA, ppx, ytA), hB = easu_pixel_terms(anaB, ppx, ytB);
-  const float ox[4] = {-1.0f - ppx, 0.0f - ppx, 1.0f - ppx, 2.0f - ppx};
-  const float sA[4] = {hA.sm, hA.s0, hA.s1, hA.s2}, bA[4] = {hA.bm, hA.b0, hA.b1, hA.b2};
-  const float sB[4] = {hB.sm, hB.s0, hB.s1, hB.s2}, bB[4] = {hB.bm, hB.b0, hB.b1, hB.b2};
-  float aR = 0.f, aG = 0.f, aB = 0.f, aW = 0.f, bR = 0.f, bG = 0.f, bBl = 0.f, bW = 0.f;
-  auto uses = [](int dx, int dy) { return dy >= -1 && dy <= 2 && ((dy == 0 || dy == 1) ? (dx >= -1 && dx <= 2) : (dx == 0 || dx == 1)); };
-#pragma unroll
-  for (int r = 0; r < 4 + S; ++r) {
-#pragma unroll
-    for (int c = -1; c <= 2; ++c) {
-      const int dyA = r - 1, dyB = r - 1 - S;  // this texel as a tap of A / of B
-      const bool forA = uses(c, dyA), forB = uses(c, dyB);
-      if (!forA && !forB) continue;
-      const float4_t t = tex(c, r);
-      if (forA) {
-        const float w = easu_tap_weight(hA, ox[c + 1], sA[dyA + 1], bA[dyA + 1]);
-        if (c == 0 && dyA == -1) { aW = w; aR = t.x * aW; aG = t.y * aW; aB = t.z * aW; }  // the first tap starts the sums
-        else { aR = fmaf(t.x, w, aR); aG = fmaf(t.y, w, aG); aB = fmaf(t.z, w, aB); aW += w; }
-      }
-      if (forB) {
-        const float w = easu_tap_weight(hB, ox[c + 1], sB[dyB + 1], bB[dyB + 1]);
-        if (c == 0 && dyB == -1) { bW = w; bR = t.x * bW; bG = t.y * bW; bBl = t.z * bW; }
-        else { bR = fmaf(t.x, w, bR); bG = fmaf(t.y, w, bG); bBl = fmaf(t.z, w, bBl); bW += w; }
-      }
-    }
-  }
-  const float rA = __builtin_amdgcn_rcpf(aW), rB = __builtin_amdgcn_rcpf(bW);
-  outA = rgbf_t{pinned(aR * rA), pinned(aG * rA), pinned(aB * rA)};
-  outB = rgbf_t{pinned(bR * rB), pinned(bG * rB), pinned(bBl * rB)};
-}
-
-// The vertical pair on a staged footprint: pixel A's texel 'f' at f_idx, pixel B's S rows below; both dering bounds are taken of
-// the tap values on the way.
-template <int S>
-__device__ __forceinline__ void easu_pixel_vpair(const EasuLds& l, int f_idx, float ppx, const EasuRowTerms& ytA, const EasuRowTerms& ytB,
-                                                 EasuBounds& mA, EasuBounds& mB, rgbf_t& pA, rgbf_t& pB) {
-  const int fw = l.fw;
-  const float4_t* const w0 = l.tex + (f_idx - fw - 1);
-  const float4_t* const a0 = w0 + (l.ana - l.tex);
-  float4_t q[3][2] = {};  // the centre columns of window rows 1 .. 3: f g / j k of A are rows 1 2, of B rows 1 + S, 2 + S
-  easu_filter_vpair<S>(
-      [&](int c, int r) {
-        const float4_t v = w0[r * fw + (c + 1)];
-        if ((c == 0 || c == 1) && r >= 1 && r <= 2 + S) q[r - 1][c] = v;
-        return v;
-      },
-      [&](int k) { return a0[((k >> 1) + 1) * fw + (k & 1) + 1]; },
-      [&](int k) { return a0[((k >> 1) + 1 + S) * fw + (k & 1) + 1]; }, ppx, ytA, ytB, pA, pB);
-  mA = easu_bounds(q[0][0], q[0][1], q[1][0], q[1][1]);
-  mB = easu_bounds(q[S][0], q[S][1], q[1 + S][0], q[1 + S][1]);
-}
-
 // A row of an exact-2x quad (sub-texel columns 1/4 and 3/4) on a staged footprint; WITH_BOUNDS takes the quad's dering bounds
 // of the tap values on the way.
 template <bool WITH_BOUNDS>
