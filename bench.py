@@ -569,8 +569,9 @@ def main():
                        "launch": launch_style(), "world_size_seen": dist.get_world_size() if world > 1 else 1,
                        "collective_backend": (("rccl (torch.distributed 'nccl')" if args.backend == "nccl" else "gloo") if world > 1 else None),
                        "devices_visible": n_dev, "oversubscribed": bool(world > n_dev),
-                       "k_dependence": "the timed region is host-clocked around K steps: at the driver's K = 20 (1.4 ms) the first launch's latency and the "
-                                       "closing synchronize are 4-6 % of it (round 2: 117.7 Gpix/s at K = 20, 122-126 at K >= 300 on the same kernels)",
+                       "k_dependence": "the timed region is host-clocked around K steps: at K = 20 (1.3 ms) the first launch's latency and the closing "
+                                       "synchronize are 1-6 % of it (round 3, one box: 124.4 Gpix/s at K = 20, 125.9 at K = 2000; round 2's driver run: 117.7 at "
+                                       "K = 20 against 122-126 at K >= 300 on the same kernels)",
                        "pipeline": args.pipeline, "storage": args.storage, "color_stages": args.stages, "hip_graph_steps": args.graph, "rcas_sharpness_stops": 0.25,
                        "parallelism": "independent frames per GPU, counters-only collective"},
             "per_rank_seconds": [round(t, 6) for t in per_rank_seconds],
