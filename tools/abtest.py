@@ -95,7 +95,7 @@ def main():
         for lib in libs:
             env = dict(os.environ)
             env.pop("FSR1_AB_FLAGS", None)
-            if "@" in lib:  # `path@flags`: the library (empty = the tree's) with extra dispatch flag bits, e.g. @0x800 = FSR1_FLAG_EASU_MATRIX_PIPE
+            if "@" in lib:  # `path@flags`: the library (empty = the tree's) with extra dispatch flag bits, e.g. @0x10 = FSR1_FLAG_MATH_EXACT
                 lib, env["FSR1_AB_FLAGS"] = lib.split("@", 1)
             if lib:
                 env["FSR1_HIP_LIB"] = os.path.join(ROOT, lib)
