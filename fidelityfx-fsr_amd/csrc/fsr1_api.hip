@@ -49,6 +49,18 @@ __global__ void selftest_kernel(uint32_t* failures) {
   if (fb != ib && !both_nan) atomicAdd(failures, 1u);
 }
 
+//   rcp_ieee(x) != 1.0f / x for any of the 2^32 binary32 operands (NaN results compare equal)
+__global__ void selftest_rcp_kernel(uint32_t* failures) {
+  const unsigned long long n = 1ull << 32, stride = (unsigned long long)gridDim.x * blockDim.x;
+  uint32_t bad = 0;
+  for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float x = __uint_as_float((uint32_t)i);
+    const float got = rcp_ieee(x), want = 1.0f / x;
+    if (__float_as_uint(got) != __float_as_uint(want) && !(got != got && want != want)) ++bad;
+  }
+  if (bad) atomicAdd(failures, bad);
+}
+
 // Tracing: with FSR1_ROCTX=1 in the environment every dispatch is wrapped in a roctx range named
 // after the pass and its extents, so rocprofv3 --marker-trace / a timeline viewer shows the frame structure.  the roctx library
 // (librocprofiler-sdk-roctx / libroctx64) is resolved with dlopen on first use: the library has no link-time dependency on it and pays one branch when off.
@@ -598,6 +610,7 @@ int fsr1_selftest(uint32_t* failures) {
   e = hipMemset(d, 0, sizeof(uint32_t));
   if (e == hipSuccess) {
     hipLaunchKernelGGL(selftest_kernel, dim3(256), dim3(256), 0, nullptr, d);
+    hipLaunchKernelGGL(selftest_rcp_kernel, dim3(256 * 32), dim3(256), 0, nullptr, d);  // all 2^32 operands: well under a second
     e = hipGetLastError();
   }
   if (e == hipSuccess) e = hipMemcpy(failures, d, sizeof(uint32_t), hipMemcpyDeviceToHost);

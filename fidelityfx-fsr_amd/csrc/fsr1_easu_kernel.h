@@ -79,17 +79,22 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(7
           continue;
         }
       }
-      const EasuBounds m = easu_bounds(l, f_idx);  // one 2x2 block for the whole quad
       if (EXACT && xin0 && xin1 && yin0 && yin1) {
-        // the whole quad lies inside the image (every lane of every tile but those on the image's border): no predicates
-        const texel_t p00 = easu_resolve<FMT, EXACT>(m, easu_pixel<EXACT>(l, f_idx, 0.25f, 0.25f), hdr);
-        const texel_t p10 = easu_resolve<FMT, EXACT>(m, easu_pixel<EXACT>(l, f_idx, 0.75f, 0.25f), hdr);
-        const texel_t p01 = easu_resolve<FMT, EXACT>(m, easu_pixel<EXACT>(l, f_idx, 0.25f, 0.75f), hdr);
-        const texel_t p11 = easu_resolve<FMT, EXACT>(m, easu_pixel<EXACT>(l, f_idx, 0.75f, 0.75f), hdr);
+        // EXACT: the per-pixel form, with the quad's four analyses loaded once and its bounds taken of the first pixel's taps (52
+        // instead of 60 LDS reads per quad, 70 VGPRs: -1 .. -2 %, profiles/ab_r03/r3c16_exact_shared_analyses_ab.log); its row
+        // pair would not fit the register budget.  (No predicates: the whole quad lies inside the image.)
+        const float4_t A[4] = {l.ana[f_idx], l.ana[f_idx + 1], l.ana[f_idx + kS2W], l.ana[f_idx + kS2W + 1]};
+        EasuBounds m;
+        const rgbf_t q00 = easu_quad_pixel<EXACT, true>(l, f_idx, 0.25f, 0.25f, A, m);
+        const texel_t p00 = easu_resolve<FMT, EXACT>(m, q00, hdr);
+        const texel_t p10 = easu_resolve<FMT, EXACT>(m, easu_quad_pixel<EXACT, false>(l, f_idx, 0.75f, 0.25f, A, m), hdr);
+        const texel_t p01 = easu_resolve<FMT, EXACT>(m, easu_quad_pixel<EXACT, false>(l, f_idx, 0.25f, 0.75f, A, m), hdr);
+        const texel_t p11 = easu_resolve<FMT, EXACT>(m, easu_quad_pixel<EXACT, false>(l, f_idx, 0.75f, 0.75f, A, m), hdr);
         store_out<sizeof(texel_t)>(o0, TexelPair<FOUT>::make(p00, p10), stream);
         store_out<sizeof(texel_t)>(o0 + a.out.pitch, TexelPair<FOUT>::make(p01, p11), stream);
         continue;
       }
+      const EasuBounds m = easu_bounds(l, f_idx);  // (border quads) one 2x2 block for the whole quad
       auto row = [&](char* o, bool yin, float ppy) {
         if (!yin) return;
         if (xin0) store_out<sizeof(texel_t)>(o, easu_resolve<FMT, EXACT>(m, easu_pixel<EXACT>(l, f_idx, 0.25f, ppy), hdr), stream);

@@ -48,6 +48,20 @@ __device__ __forceinline__ float sat(float x) { return fminf(fmaxf(x, 0.0f), 1.0
 template <bool EXACT>
 __device__ __forceinline__ float mad(float a, float b, float c) { return EXACT ? a * b + c : fmaf(a, b, c); }
 
+// The correctly rounded reciprocal 1.0f / x of the EXACT variants (GLSL `1.0 / x`, ARcpF1: the oracle's pin), in 6 instructions
+// instead of the 11 of the general IEEE division: one Newton step from v_rcp_f32 (1 ulp) is the correctly rounded quotient for
+// EVERY operand with a biased exponent in 1 .. 252 — checked bit for bit over all 2^32 operands on the device
+// (fsr1_selftest, tools/ubench/rcp_exhaustive.hip) — v_div_fixup_f32 supplies the IEEE results for 0, inf and NaN, and the
+// operands that are left (denormal x, and |x| >= 2^126 whose quotient is denormal) take the general division behind a branch no
+// image value ever takes.
+__device__ __forceinline__ float rcp_ieee(float x) {
+  const float y = __builtin_amdgcn_rcpf(x);
+  const float y1 = fmaf(y, fmaf(-x, y, 1.0f), y);
+  float r = __builtin_amdgcn_div_fixupf(y1, x, 1.0f);
+  if (__builtin_expect(__builtin_amdgcn_classf(x, 0x090) || fabsf(x) >= 0x1.0p+126f, 0)) r = 1.0f / x;  // 0x090: -denormal | +denormal
+  return r;
+}
+
 // Optimisation barrier for a value that is about to be narrowed.  LLVM folds fptrunc(fmul) / fptrunc(fma)
 // into v_fma_mixlo_f16 even with -ffp-contract=off, i.e. ONE rounding of the exact product to binary16
 // instead of the reference's binary32 product followed by the store's rounding.  The EXACT variants pin

@@ -37,7 +37,7 @@ constexpr uint32_t kColorNeedsNoise = FSR1_COLOR_LFGA | FSR1_COLOR_DITHER_FROM_N
 struct rgb3_t { float r, g, b; };
 
 template <bool EXACT>
-__device__ __forceinline__ float color_rcp(float x) { return EXACT ? 1.0f / x : __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float color_rcp(float x) { return EXACT ? rcp_ieee(x) : __builtin_amdgcn_rcpf(x); }
 
 // :1042 FsrSrtmF
 template <bool EXACT>

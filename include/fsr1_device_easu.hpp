@@ -291,6 +291,8 @@ __device__ __forceinline__ rgbf_t easu_filter(const Tex& tex, const Ana& ana, fl
     tap(0, 2, ox0, s2, b2); tap(1, 2, ox1, s2, b2);
   }
   // :437 normalise (dering clamp is applied by the caller)
+  // (EXACT: the general IEEE division, not rcp_ieee — one reciprocal per pixel saves five instructions of eight hundred, and its
+  //  never-taken branch in the middle of the filter costs the exact-2x kernel 4 %: profiles/ab_r03/r3c15_exact_rcp_ieee_ab.log)
   const float rW = EXACT ? 1.0f / aW : __builtin_amdgcn_rcpf(aW);
   // pinned in every variant: the narrowing that follows must round the binary32 product, not re-fuse it
   // (v_fma_mixlo_f16), or two kernels sharing this code could round the same pixel differently

@@ -31,9 +31,9 @@ __device__ __forceinline__ rgb_t rcas_pixel(rgb_t b, rgb_t d, rgb_t e, rgb_t f, 
   // instructions per two pixels in the streaming kernel).  The instructions themselves are IEEE minNum / maxNum.
   const float mn4R = vmin2(vmin3(b.r, d.r, f.r), h.r), mn4G = vmin2(vmin3(b.g, d.g, f.g), h.g), mn4B = vmin2(vmin3(b.b, d.b, f.b), h.b);
   const float mx4R = vmax2(vmax3(b.r, d.r, f.r), h.r), mx4G = vmax2(vmax3(b.g, d.g, f.g), h.g), mx4B = vmax2(vmax3(b.b, d.b, f.b), h.b);
-  // :748-755 limiters; "these need to be high precision RCPs": IEEE division when EXACT, v_rcp_f32 (1 ulp) otherwise.
+  // :748-755 limiters; "these need to be high precision RCPs": the correctly rounded reciprocal when EXACT (rcp_ieee), v_rcp_f32 (1 ulp) otherwise.
   // 4*x and 4*x-4 are exact scalings, so fusing the latter does not change it (barring overflow).
-  auto rcp = [](float x) { return EXACT ? 1.0f / x : __builtin_amdgcn_rcpf(x); };
+  auto rcp = [](float x) { return EXACT ? rcp_ieee(x) : __builtin_amdgcn_rcpf(x); };
   const float hitMinR = vmin2(mn4R, e.r) * rcp(4.0f * mx4R);
   const float hitMinG = vmin2(mn4G, e.g) * rcp(4.0f * mx4G);
   const float hitMinB = vmin2(mn4B, e.b) * rcp(4.0f * mx4B);

@@ -277,9 +277,10 @@ int fsr1_version(void);
 /* Number of HIP devices visible, or a negative fsr1_status. */
 int fsr1_device_count(void);
 
-/* Exhaustive on-device check of the hardware assumptions behind the packed-binary16 kernels (all 65536
- * binary16 operands): *failures = number of operands for which the kernels' reciprocal differs from the
- * correctly rounded 1/x that the reference's ARcpH1/ARcpH2 (ffx_a.h:1005, GLSL `1.0/x`) are pinned to. */
+/* Exhaustive on-device check of the hardware assumptions behind the kernels' reciprocals: *failures = number of operands
+ * for which (a) the packed-binary16 kernels' reciprocal (all 65536 binary16 operands) or (b) the EXACT variants' binary32
+ * reciprocal (rcp_ieee, include/fsr1_device_base.hpp: all 2^32 binary32 operands) differs from the correctly rounded 1/x
+ * that the reference's ARcpH1/ARcpH2/ARcpF1 (ffx_a.h:1005, GLSL `1.0/x`) are pinned to. */
 int fsr1_selftest(uint32_t* failures);
 
 /* HIP-event stopwatch on a caller stream (used by the bench so that kernel time is measured on the
