@@ -52,6 +52,8 @@ WORKLOADS = {
     "1662p_to_4k": (2954, 1662, 3840, 2160, 1),          # 1.3x "Ultra Quality"
     "1440p_to_4k_x8": (2560, 1440, 3840, 2160, 8),       # configs[2]: 64 frames over 8 GPUs
     "4k_to_8k_x16": (3840, 2160, 7680, 4320, 16),        # configs[4]: 128 frames over 8 GPUs
+    "4k_to_8k": (3840, 2160, 7680, 4320, 1),             # one 8K frame
+    "1080p_to_4k_x4": (1920, 1080, 3840, 2160, 4),       # four 4K frames per launch (the exact-2x shape as a small batch)
 }
 
 
@@ -81,15 +83,19 @@ def gather_seconds(seconds, device):
     return [float(t.item()) for t in out]
 
 
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
 def self_launch(argv, n):
     """`python bench.py --gpus N` with no WORLD_SIZE in the environment: start the N ranks the way the driver's other launch
     style does — python -m torch.distributed.run --nnodes=1 --nproc-per-node N on 127.0.0.1 — and hand back its exit code.
     Rank 0's JSON line reaches this process's stdout unchanged (torchrun passes the workers' stdout through)."""
-    import socket
     import subprocess
-    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
+    port = free_port()
     env = dict(os.environ, FSR1_BENCH_SELF_LAUNCHED="1", MASTER_ADDR="127.0.0.1")
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL across processes needs it on these hosts
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
@@ -239,6 +245,9 @@ def main():
     ap.add_argument("--oversubscribe", action="store_true",
                     help="with --backend gloo: let ranks share GPUs (rank r runs on device r %% visible devices) — exercises the N-rank launch on a one-GPU box; "
                          "the line says so and its value is not a scaling figure")
+    ap.add_argument("--collective", default="auto", choices=["auto", "always"],
+                    help="auto: a process group only when there is more than one rank; always: also at N = 1, so that RCCL's communicator, "
+                         "barrier, all-reduce and all-gather run on a one-GPU box exactly as they do at N > 1")
     ap.add_argument("--stub", action="store_true", help="test fixture: the N-rank plumbing over gloo with no GPU work (data = 'stub')")
     args = ap.parse_args()
 
@@ -271,8 +280,11 @@ def main():
     dev_index = local_rank % n_dev
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
-    if world > 1:
+    grouped = world > 1 or args.collective == "always"
+    if grouped:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1 and "MASTER_PORT" not in os.environ:  # a bare `python bench.py --collective always`
+            os.environ.update(MASTER_PORT=str(free_port()), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=device)  # "nccl" is RCCL on ROCm
         else:
@@ -345,7 +357,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if grouped:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -357,7 +369,7 @@ def main():
         is then the time at which the slowest rank finished its K steps."""
         torch.cuda.synchronize()
         t = time.perf_counter()
-        if world > 1:
+        if grouped:
             dist.barrier()
             torch.cuda.synchronize()
         return t
@@ -566,8 +578,8 @@ def main():
                                    + (" (inputs / outputs; one reused intermediary)" if args.pipeline == "two-pass" else ""),
                        "source_hash": fsr._lib.source_hash(),
                        "intermediary": None if args.pipeline != "two-pass" else ("rotated" if args.rotate_intermediary else "reused"),
-                       "launch": launch_style(), "world_size_seen": dist.get_world_size() if world > 1 else 1,
-                       "collective_backend": (("rccl (torch.distributed 'nccl')" if args.backend == "nccl" else "gloo") if world > 1 else None),
+                       "launch": launch_style(), "world_size_seen": dist.get_world_size() if grouped else 1,
+                       "collective_backend": (("rccl (torch.distributed 'nccl')" if args.backend == "nccl" else "gloo") if grouped else None),
                        "devices_visible": n_dev, "oversubscribed": bool(world > n_dev),
                        "k_dependence": "the timed region is host-clocked around K steps: at K = 20 (1.3 ms) the first launch's latency and the closing "
                                        "synchronize are 1-6 % of it (round 3, one box: 124.4 Gpix/s at K = 20, 125.9 at K = 2000; round 2's driver run: 117.7 at "
@@ -585,7 +597,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline and args.pipeline != "color" and not args.stages:
             line["cpu_baseline"] = cpu_baseline(fsr, in_w, in_h, out_w, out_h)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if grouped:
         dist.destroy_process_group()
 
 

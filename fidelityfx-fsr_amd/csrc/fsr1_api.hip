@@ -20,9 +20,9 @@ hipError_t fused_launch(const FusedArgs& a, int fmt, bool exact, hipStream_t str
 size_t fused_lds_bytes(int fmt, int fp_w, int fp_h);
 hipError_t fused_h_launch(const FusedArgs& a, hipStream_t stream);
 hipError_t fused_s2_launch(const FusedArgs& a, int fmt, bool exact, hipStream_t stream);
-size_t fused_s2_lds_bytes(int fmt, int qh);
-void fused_s2_geometry(int width, int height, int qh, int* tiles_x, int* tiles_y);
-int fused_s2_quad_rows();
+size_t fused_s2_lds_bytes(int fmt);
+void fused_s2_geometry(int width, int height, int steps, int* tiles_x, int* tiles_y);
+int fused_s2_run_steps(int width, int height, int frames);
 size_t fused_h_lds_bytes(int fp_w, int fp_h);
 hipError_t easu_h_launch(const EasuArgs& a, bool s2, hipStream_t stream);
 hipError_t easu_color_launch(const EasuArgs& a, int fin, int fout, bool exact, hipStream_t stream);
@@ -487,8 +487,9 @@ static int fused_dispatch_impl(const fsr1_image* in, const fsr1_image* out, cons
   // of the apron tile (fsr1_fused_s2.hip); its tiles are 62 pixels wide and 2 QH - 2 tall.
   const bool s2 = easu_con[0] == 0x3f000000u && easu_con[1] == 0x3f000000u && easu_con[2] == 0xbe800000u && easu_con[3] == 0xbe800000u &&
                   !(flags & FSR1_FLAG_NO_FAST_PATHS) && !packed && !a.color.stages && !(origin_y & 1) &&
-                  fused_s2_lds_bytes(in->format, fused_s2_quad_rows()) <= 160 * 1024;
-  if (s2) fused_s2_geometry(out->width, out->height, fused_s2_quad_rows(), &a.tiles_x, &a.tiles_y);
+                  fused_s2_lds_bytes(in->format) <= 160 * 1024;
+  a.run_steps = s2 ? fused_s2_run_steps(out->width, out->height, out->frames) : 0;
+  if (s2) fused_s2_geometry(out->width, out->height, a.run_steps, &a.tiles_x, &a.tiles_y);
   if ((rc = check_grid("fused", a.tiles_x, a.tiles_y, a.frames))) return rc;
   a.flags = resolve_output_policy(flags, true);
   const bool exact = (flags & FSR1_FLAG_MATH_EXACT) != 0;

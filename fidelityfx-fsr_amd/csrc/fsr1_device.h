@@ -64,6 +64,7 @@ struct FusedArgs {
   // band of a larger output image (fsr1_easu_rcas_fused_dispatch_band): output row 0 is row origin_y of the image the EASU
   // constants describe; rows_above / rows_below (0 or 1): that image has a row above / below the band, which the apron computes
   int origin_y, rows_above, rows_below;
+  int run_steps;  // exact-2x kernel (fsr1_fused_s2.hip): 16-row steps a workgroup walks down its column
 };
 
 // XCD-aware workgroup -> tile mapping.  Consecutive workgroup ids round-robin over the 8 XCDs

@@ -3,10 +3,14 @@
 // The generic fused kernel (fsr1_fused_kernel.h) runs EASU one pixel at a time on its apron tile; at exactly 2x the EASU
 // kernel's quad form applies (fsr1_easu_kernel.h, S2): output pixels 2j+1 and 2j+2 share the texel f = j with sub-texel
 // positions 1/4 and 3/4, so a 2x2 quad shares window address, analyses and dering bounds, and every position constant
-// is a literal.  The tile is chosen so that its apron is a whole number of quads per lane and of columns per wave:
-//   output tile   62 x (2 QH - 2) pixels at (62 tx, (2 QH - 2) ty)
-//   apron tile    64 x 2 QH pixels from (62 tx - 1, (2 QH - 2) ty - 1): odd origin = quad-aligned, 32 x QH quads = QH / 8 per lane
-//   footprint     35 x (QH + 3) texels from (31 tx - 2, (QH - 1) ty - 2)
+// is a literal.  A workgroup owns a 62-pixel column of the output and walks DOWN it in steps of 16 EASU rows (round 3; before,
+// every 16-row apron tile gave 14 output rows and the two apron rows were computed twice):
+//   step s of run ty   EASU rows [Y0 - 1 + 16 s, Y0 + 14 + 16 s], Y0 = (16 S - 2) ty — 32 x 8 quads, one per lane, from an odd
+//                      (= quad-aligned) origin, written to an LDS ring of 18 rows: the 16 new ones and the last two of step s - 1
+//   footprint          35 x 11 texels from (31 tx - 2, Y0 / 2 + 8 s - 2)
+//   RCAS               the 16 rows whose three EASU rows are in the ring (14 in step 0): four per wave
+// so a run of S steps computes 16 S EASU rows for 16 S - 2 output rows: the vertical apron is paid once per run instead of once
+// per tile (S = 1 is the old tile).  S comes from the host (FusedArgs::run_steps): as many steps as keep every CU supplied.
 // Phase 4 (RCAS) has lane L own apron column L: lanes 1 .. 62 are the tile's output columns and lanes 0 / 63 the apron
 // columns themselves, so both horizontal neighbours of every output pixel arrive by DPP wave shifts and nothing but the
 // lane's own column is read from LDS.  Same per-pixel functions on the same values as the generic kernel and as the two
@@ -19,25 +23,42 @@
 namespace fsr1 {
 
 constexpr int kFs2OutW = 62, kFs2MidW = 64, kFs2FpW = 35;
+constexpr int kFs2QH = 8, kFs2FpH = kFs2QH + 3, kFs2Step = 2 * kFs2QH, kFs2Ring = kFs2Step + 2;  // quad rows, footprint rows, EASU rows per step, ring rows
 
-size_t fused_s2_lds_bytes(int fmt, int qh) {
+size_t fused_s2_lds_bytes(int fmt) {
   const size_t texel = fmt == FSR1_FORMAT_RGBA32F ? 16 : (fmt == FSR1_FORMAT_RGBA16F ? 8 : 4);
-  return easu_lds_region_bytes((size_t)kFs2FpW * (qh + 3)) + (size_t)kFs2MidW * 2 * qh * texel;
+  return easu_lds_region_bytes((size_t)kFs2FpW * kFs2FpH) + (size_t)kFs2MidW * kFs2Ring * texel;
 }
 
-void fused_s2_geometry(int width, int height, int qh, int* tiles_x, int* tiles_y) {
+// Steps per run: one workgroup per (column, run).  With S steps a run wastes 2 of 16 S EASU rows, so S wants to be large; but a
+// launch wants every CU supplied to its end, and a run is S times as long as a tile: measured (profiles/ab_r03/r3c17..r3c19), a
+// single 4K frame (9 610 one-step tiles, five residencies of 256 CUs x 7 workgroups) loses with any S > 1 (2: +3 %, 3: +8 %,
+// 5: +18 %), four 4K frames or one 8K frame (38 440) gain 4.5 % at S = 4 (2: 1-2 %, 6: 2 %, 8: -1 %), sixteen 8K frames
+// (613 000) gain 6.3 % at S = 8 (6: 5.7 %, 10: 5.9 %, 16: 4.5 %) — so: about five residencies of runs, at most 8 steps.
+#ifndef FSR1_FUSED_S2_MAX_STEPS
+#define FSR1_FUSED_S2_MAX_STEPS 8
+#endif
+int fused_s2_run_steps(int width, int height, int frames) {
+  if (const char* e = getenv("FSR1_FUSED_S2_STEPS"); e && atoi(e) > 0) return atoi(e);  // tuning runs and tests/test_gpu_parity.py: any S gives the same image
+  const long long tiles1 = (long long)((width + kFs2OutW - 1) / kFs2OutW) * ((height + kFs2Step - 3) / (kFs2Step - 2)) * frames;
+  const long long s = tiles1 / (5 * 256 * 7);
+  return (int)(s < 1 ? 1 : s > FSR1_FUSED_S2_MAX_STEPS ? FSR1_FUSED_S2_MAX_STEPS : s);
+}
+
+void fused_s2_geometry(int width, int height, int steps, int* tiles_x, int* tiles_y) {
+  const int run = kFs2Step * steps - 2;
   *tiles_x = (width + kFs2OutW - 1) / kFs2OutW;
-  *tiles_y = (height + (2 * qh - 2) - 1) / (2 * qh - 2);
+  *tiles_y = (height + run - 1) / run;
 }
 
-template <int FMT, bool EXACT, int QH>
+// RUN = false: the one-step launch (run_steps == 1), compiled without the step loop and the ring arithmetic.
+template <int FMT, bool EXACT, bool RUN>
 __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(7, 8))) fused_s2_kernel(const FusedArgs a) {  // (<= 72 VGPRs: 7 workgroups per CU is what its LDS admits)
   typedef typename Pixel<FMT>::T texel_t;
-  static_assert(QH % 8 == 0 && kThreads == 256, "32 x QH quads over 256 lanes");
-  constexpr int kFpH = QH + 3, kOutH = 2 * QH - 2;  // (the apron tile is 2 QH rows tall)
+  static_assert(kFs2QH == 8 && kThreads == 256, "32 x 8 quads over 256 lanes");
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  EasuLds l = easu_lds_carve(smem, kFs2FpW * kFpH);
-  texel_t* const mid = reinterpret_cast<texel_t*>(smem + easu_lds_region_bytes(kFs2FpW * kFpH));  // [kMidH][64]
+  EasuLds l = easu_lds_carve(smem, kFs2FpW * kFs2FpH);
+  texel_t* const mid = reinterpret_cast<texel_t*>(smem + easu_lds_region_bytes(kFs2FpW * kFs2FpH));  // [kFs2Ring][64], a ring of rows
 
   const int tiles_per_frame = a.tiles_x * a.tiles_y;
   const int t = xcd_swizzle(blockIdx.x, tiles_per_frame * a.frames);
@@ -45,107 +66,132 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(7
   const int tf = t - frame * tiles_per_frame;
   const int ty = tf / a.tiles_x, tx = tf - ty * a.tiles_x;
   const int W = a.out.width, H = a.out.height;
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
 
   l.fw = kFs2FpW;
   // (a band of a larger output image, fsr1_easu_rcas_fused_dispatch_band: output row 0 is row a.origin_y — even, the host
   //  checks — of the image the constants describe, and the rows just above / below the band exist there when rows_above /
   //  rows_below say so: the apron computes them instead of taking them as outside the image)
-  easu_stage_footprint<FMT, false, EXACT, kFs2FpW, kFpH>(l, a.in, a.in.base + (long long)frame * a.in.frame_stride, 31 * tx - 2,
-                                                         (QH - 1) * ty - 2 + (a.origin_y >> 1), kFs2FpW, kFpH, tid);
   const int ylo = -a.rows_above, yhi = H - 1 + a.rows_below;
-
-  // ---- phase 3: EASU on the apron tile, a quad per lane and iteration, rounded to the storage format (EASU runs with
-  //      Sample.x = 0 when RCAS follows: FSR_Filter.cpp:107); pixels outside the image are 0 (FSR_Pass.hlsl:45,61) ----
-  const int ax0 = kFs2OutW * tx - 1, ay0 = kOutH * ty - 1;  // both odd
-#pragma unroll 1
-  for (int k = 0; k < QH / 8; ++k) {
-    const int qx = lane & 31, qy = 8 * k + 2 * wave + (lane >> 5);
-    const int oxa = ax0 + 2 * qx, oya = ay0 + 2 * qy;
-    const bool xin0 = oxa >= 0 && oxa < W, xin1 = oxa + 1 < W, yin0 = oya >= ylo && oya <= yhi, yin1 = oya + 1 <= yhi;
-    const int f_idx = (qy + 1) * kFs2FpW + (qx + 1);
-    texel_t* const m0 = mid + (2 * qy) * kFs2MidW + 2 * qx;
-    typedef typename TexelPair<FMT>::T pair_t;
-    if (!EXACT && xin0 && xin1 && yin0 && yin1) {  // default arithmetic: two row pairs, every texel read once per row (see easu_kernel)
-      const float4_t A[4] = {l.ana[f_idx], l.ana[f_idx + 1], l.ana[f_idx + kFs2FpW], l.ana[f_idx + kFs2FpW + 1]};
-      EasuBounds m;
-      rgbf_t q00, q10, q01, q11;
-      easu_quad_row<true>(l, f_idx, 0.25f, A, m, q00, q10);
-      *reinterpret_cast<pair_t*>(m0) = TexelPair<FMT>::make(easu_resolve<FMT, EXACT>(m, q00, false), easu_resolve<FMT, EXACT>(m, q10, false));
-      easu_quad_row<false>(l, f_idx, 0.75f, A, m, q01, q11);
-      *reinterpret_cast<pair_t*>(m0 + kFs2MidW) = TexelPair<FMT>::make(easu_resolve<FMT, EXACT>(m, q01, false), easu_resolve<FMT, EXACT>(m, q11, false));
-    } else if (xin0 && xin1 && yin0 && yin1) {  // every quad but those on the image's border
-      const EasuBounds m = easu_bounds(l, f_idx);
-      const texel_t p00 = easu_resolve<FMT, EXACT>(m, easu_pixel<EXACT>(l, f_idx, 0.25f, 0.25f), false);
-      const texel_t p10 = easu_resolve<FMT, EXACT>(m, easu_pixel<EXACT>(l, f_idx, 0.75f, 0.25f), false);
-      const texel_t p01 = easu_resolve<FMT, EXACT>(m, easu_pixel<EXACT>(l, f_idx, 0.25f, 0.75f), false);
-      const texel_t p11 = easu_resolve<FMT, EXACT>(m, easu_pixel<EXACT>(l, f_idx, 0.75f, 0.75f), false);
-      *reinterpret_cast<pair_t*>(m0) = TexelPair<FMT>::make(p00, p10);
-      *reinterpret_cast<pair_t*>(m0 + kFs2MidW) = TexelPair<FMT>::make(p01, p11);
-    } else {
-      texel_t p[4] = {Pixel<FMT>::zero(), Pixel<FMT>::zero(), Pixel<FMT>::zero(), Pixel<FMT>::zero()};
-      if ((xin0 || xin1) && (yin0 || yin1)) {
-        const EasuBounds m = easu_bounds(l, f_idx);
-        if (xin0 && yin0) p[0] = easu_resolve<FMT, EXACT>(m, easu_pixel<EXACT>(l, f_idx, 0.25f, 0.25f), false);
-        if (xin1 && yin0) p[1] = easu_resolve<FMT, EXACT>(m, easu_pixel<EXACT>(l, f_idx, 0.75f, 0.25f), false);
-        if (xin0 && yin1) p[2] = easu_resolve<FMT, EXACT>(m, easu_pixel<EXACT>(l, f_idx, 0.25f, 0.75f), false);
-        if (xin1 && yin1) p[3] = easu_resolve<FMT, EXACT>(m, easu_pixel<EXACT>(l, f_idx, 0.75f, 0.75f), false);
-      }
-      m0[0] = p[0]; m0[1] = p[1]; m0[kFs2MidW] = p[2]; m0[kFs2MidW + 1] = p[3];
-    }
-  }
-  __syncthreads();
-
-  // ---- phase 4: RCAS from the LDS tile.  Lane L owns apron column L; a wave walks down its share of the kOutH rows with
-  //      b / e / h in registers, d and f are the neighbouring lanes' centre texels (DPP wave shifts).  Every lane stays
-  //      active (DPP sources); lanes 0 / 63 and pixels outside the image store nothing. ----
-  constexpr int kRowsLo = kOutH / 4, kExtra = kOutH % 4;  // the first kExtra waves take one row more
-  const int nrows = kRowsLo + (wave < kExtra ? 1 : 0);
-  const int ry0 = wave * kRowsLo + min(wave, kExtra);
-  const int ox = ax0 + lane;
+  const int steps = RUN ? a.run_steps : 1;
+  const int Y0 = (kFs2Step * steps - 2) * ty;  // the run's first output row (even)
+  const int ax0 = kFs2OutW * tx - 1;           // odd, like every step's first EASU row
   const float sharp = as_f32(a.rcas_con[0]);
   const uint32_t flags = a.flags;
   const bool stream = (flags & FSR1_FLAG_OUTPUT_STREAMING) != 0;
-  const bool col_ok = lane >= 1 && lane <= kFs2OutW && ox < W;
-  char* const out_col = a.out.base + (long long)frame * a.out.frame_stride + (long long)ox * (long long)sizeof(texel_t);
+  char* const out_frame = a.out.base + (long long)frame * a.out.frame_stride;
   auto rgb = [](const texel_t& p) { const float4_t c = Pixel<FMT>::load(p); return rgb_t{c.x, c.y, c.z}; };
-  const texel_t* c = mid + (ry0 + 1) * kFs2MidW + lane;  // centre texel of this lane's first row
-  rgb_t prev = rgb(c[-kFs2MidW]);
-  texel_t e_raw = c[0];
-  rgb_t cur = rgb(e_raw);
-#pragma unroll
-  for (int r = 0; r < kRowsLo + (kExtra ? 1 : 0); ++r, c += kFs2MidW) {
-    if (r >= nrows) break;  // wave-uniform
-    const int oy = ay0 + 1 + ry0 + r;
-    const texel_t n_raw = c[kFs2MidW];
-    const rgb_t next = rgb(n_raw);
-    const rgb_t d = rgb_t{dpp_f32<kDppWaveShr1>(cur.r, cur.r), dpp_f32<kDppWaveShr1>(cur.g, cur.g), dpp_f32<kDppWaveShr1>(cur.b, cur.b)};
-    const rgb_t f = rgb_t{dpp_f32<kDppWaveShl1>(cur.r, cur.r), dpp_f32<kDppWaveShl1>(cur.g, cur.g), dpp_f32<kDppWaveShl1>(cur.b, cur.b)};
-    const rgb_t p = rcas_pixel<EXACT>(prev, d, cur, f, next, sharp, flags);
-    if (col_ok && oy < H) {
-      const float pa = (flags & FSR1_FLAG_RCAS_PASSTHROUGH_ALPHA) ? Pixel<FMT>::load(e_raw).w : 1.0f;
-      store_out<sizeof(texel_t)>(out_col + (long long)oy * a.out.pitch, Pixel<FMT>::store(p.r, p.g, p.b, pa), stream);
+  typedef typename TexelPair<FMT>::T pair_t;
+
+  const char* const in_frame = a.in.base + (long long)frame * a.in.frame_stride;
+
+  // Ring row j of step s (j = 0, 1: the last two EASU rows of step s - 1; j = 2 .. 17: this step's) is EASU row ay0 + j - 2 and
+  // sits in ring slot (base + j) mod 18, base = 16 s mod 18.
+  int base = 0;
+#pragma unroll 1
+  for (int s = 0; s < steps; ++s) {
+    const int ay0 = Y0 - 1 + kFs2Step * s;  // first EASU row of this step
+    // (step 0 is inside the image by the launch's geometry; a later step runs only if the previous one found it inside)
+    int tid = threadIdx.x;
+    if (RUN) asm volatile("" : "+v"(tid));  // per-lane addresses are re-derived in every step rather than kept in registers across the filter
+    const int lane = tid & 63;
+    easu_stage_footprint<FMT, false, EXACT, kFs2FpW, kFs2FpH>(l, a.in, in_frame, 31 * tx - 2, ((ay0 + 1) >> 1) - 2 + (a.origin_y >> 1), kFs2FpW,
+                                                             kFs2FpH, tid);
+    // (its two barriers also separate this step's ring writes from the previous step's RCAS reads)
+
+    // ---- phase 3: EASU on the step's 64 x 16 pixels, a quad per lane, rounded to the storage format (EASU runs with
+    //      Sample.x = 0 when RCAS follows: FSR_Filter.cpp:107); pixels outside the image are 0 (FSR_Pass.hlsl:45,61) ----
+    {
+      const int qx = lane & 31, qy = 2 * wave + (lane >> 5);
+      const int oxa = ax0 + 2 * qx, oya = ay0 + 2 * qy;
+      const bool xin0 = oxa >= 0 && oxa < W, xin1 = oxa + 1 < W, yin0 = oya >= ylo && oya <= yhi, yin1 = oya + 1 <= yhi;
+      const int f_idx = (qy + 1) * kFs2FpW + (qx + 1);
+      int slot = base + 2 + 2 * qy;  // even, so the quad's two rows never straddle the wrap
+      slot -= slot >= kFs2Ring ? kFs2Ring : 0;
+      texel_t* const m0 = mid + slot * kFs2MidW + 2 * qx;
+      if (!EXACT && xin0 && xin1 && yin0 && yin1) {  // default arithmetic: two row pairs, every texel read once per row (see easu_kernel)
+        const float4_t A[4] = {l.ana[f_idx], l.ana[f_idx + 1], l.ana[f_idx + kFs2FpW], l.ana[f_idx + kFs2FpW + 1]};
+        EasuBounds m;
+        rgbf_t q00, q10, q01, q11;
+        easu_quad_row<true>(l, f_idx, 0.25f, A, m, q00, q10);
+        *reinterpret_cast<pair_t*>(m0) = TexelPair<FMT>::make(easu_resolve<FMT, EXACT>(m, q00, false), easu_resolve<FMT, EXACT>(m, q10, false));
+        easu_quad_row<false>(l, f_idx, 0.75f, A, m, q01, q11);
+        *reinterpret_cast<pair_t*>(m0 + kFs2MidW) = TexelPair<FMT>::make(easu_resolve<FMT, EXACT>(m, q01, false), easu_resolve<FMT, EXACT>(m, q11, false));
+      } else if (xin0 && xin1 && yin0 && yin1) {  // every quad but those on the image's border
+        const EasuBounds m = easu_bounds(l, f_idx);
+        const texel_t p00 = easu_resolve<FMT, EXACT>(m, easu_pixel<EXACT>(l, f_idx, 0.25f, 0.25f), false);
+        const texel_t p10 = easu_resolve<FMT, EXACT>(m, easu_pixel<EXACT>(l, f_idx, 0.75f, 0.25f), false);
+        const texel_t p01 = easu_resolve<FMT, EXACT>(m, easu_pixel<EXACT>(l, f_idx, 0.25f, 0.75f), false);
+        const texel_t p11 = easu_resolve<FMT, EXACT>(m, easu_pixel<EXACT>(l, f_idx, 0.75f, 0.75f), false);
+        *reinterpret_cast<pair_t*>(m0) = TexelPair<FMT>::make(p00, p10);
+        *reinterpret_cast<pair_t*>(m0 + kFs2MidW) = TexelPair<FMT>::make(p01, p11);
+      } else {
+        texel_t p[4] = {Pixel<FMT>::zero(), Pixel<FMT>::zero(), Pixel<FMT>::zero(), Pixel<FMT>::zero()};
+        if ((xin0 || xin1) && (yin0 || yin1)) {
+          const EasuBounds m = easu_bounds(l, f_idx);
+          if (xin0 && yin0) p[0] = easu_resolve<FMT, EXACT>(m, easu_pixel<EXACT>(l, f_idx, 0.25f, 0.25f), false);
+          if (xin1 && yin0) p[1] = easu_resolve<FMT, EXACT>(m, easu_pixel<EXACT>(l, f_idx, 0.75f, 0.25f), false);
+          if (xin0 && yin1) p[2] = easu_resolve<FMT, EXACT>(m, easu_pixel<EXACT>(l, f_idx, 0.25f, 0.75f), false);
+          if (xin1 && yin1) p[3] = easu_resolve<FMT, EXACT>(m, easu_pixel<EXACT>(l, f_idx, 0.75f, 0.75f), false);
+        }
+        m0[0] = p[0]; m0[1] = p[1]; m0[kFs2MidW] = p[2]; m0[kFs2MidW + 1] = p[3];
+      }
     }
-    prev = cur; cur = next; e_raw = n_raw;
+    __syncthreads();
+
+    // ---- phase 4: RCAS from the ring.  Lane L owns apron column L; wave w takes the ring rows 1 + 4 w .. 4 + 4 w as centres
+    //      (step 0 has no rows above its row 2: its first two are left out) with b / e / h in registers; d and f are the
+    //      neighbouring lanes' centre texels (DPP wave shifts).  Every lane stays active (DPP sources); lanes 0 / 63 and pixels
+    //      outside the image store nothing. ----
+    {
+      const int ox = ax0 + lane;
+      const bool col_ok = lane >= 1 && lane <= kFs2OutW && ox < W;
+      const uint32_t col_off = (uint32_t)ox * (uint32_t)sizeof(texel_t);  // (never used when ox < 0: lane 0 stores nothing)
+      const int skip = (s == 0 && wave == 0) ? 2 : 0;
+      const int j0 = 1 + 4 * wave + skip, nrows = 4 - skip;
+      auto row = [&](int j) {  // (wave-uniform)
+        int slot = base + j;
+        slot -= slot >= kFs2Ring ? kFs2Ring : 0;
+        return mid + slot * kFs2MidW + lane;
+      };
+      rgb_t prev = rgb(*row(j0 - 1));
+      texel_t e_raw = *row(j0);
+      rgb_t cur = rgb(e_raw);
+      auto do_row = [&](int r) {
+        const int j = j0 + r, oy = ay0 + j - 2;
+        const texel_t n_raw = *row(j + 1);
+        const rgb_t next = rgb(n_raw);
+        const rgb_t d = rgb_t{dpp_f32<kDppWaveShr1>(cur.r, cur.r), dpp_f32<kDppWaveShr1>(cur.g, cur.g), dpp_f32<kDppWaveShr1>(cur.b, cur.b)};
+        const rgb_t f = rgb_t{dpp_f32<kDppWaveShl1>(cur.r, cur.r), dpp_f32<kDppWaveShl1>(cur.g, cur.g), dpp_f32<kDppWaveShl1>(cur.b, cur.b)};
+        const rgb_t p = rcas_pixel<EXACT>(prev, d, cur, f, next, sharp, flags);
+        if (col_ok && oy < H) {
+          const float pa = (flags & FSR1_FLAG_RCAS_PASSTHROUGH_ALPHA) ? Pixel<FMT>::load(e_raw).w : 1.0f;
+          store_out<sizeof(texel_t)>(out_frame + (long long)oy * a.out.pitch + col_off, Pixel<FMT>::store(p.r, p.g, p.b, pa), stream);
+        }
+        prev = cur; cur = next; e_raw = n_raw;
+      };
+      do_row(0); do_row(1);
+      if (nrows == 4) { do_row(2); do_row(3); }  // wave-uniform
+    }
+    if (!RUN || s + 1 == steps || ay0 + kFs2Step - 1 >= H) break;  // (the next step's first output row is ay0 + 15)
+    base += kFs2Step;
+    base -= base >= kFs2Ring ? kFs2Ring : 0;
   }
 }
 
-template <int FMT, bool EXACT, int QH>
+template <int FMT, bool EXACT, bool RUN>
 static hipError_t fused_s2_launch_one(const FusedArgs& a, hipStream_t stream) {
   const dim3 grid((unsigned)(a.tiles_x * a.tiles_y * a.frames)), block(kThreads);
-  const size_t lds = fused_s2_lds_bytes(FMT, QH);
-  if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&fused_s2_kernel<FMT, EXACT, QH>), lds); e != hipSuccess) return e;
-  hipLaunchKernelGGL((fused_s2_kernel<FMT, EXACT, QH>), grid, block, lds, stream, a);
+  const size_t lds = fused_s2_lds_bytes(FMT);
+  if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&fused_s2_kernel<FMT, EXACT, RUN>), lds); e != hipSuccess) return e;
+  hipLaunchKernelGGL((fused_s2_kernel<FMT, EXACT, RUN>), grid, block, lds, stream, a);
   return hipGetLastError();
 }
 
-#ifndef FSR1_FUSED_S2_QH
-#define FSR1_FUSED_S2_QH 8
-#endif
-int fused_s2_quad_rows() { return FSR1_FUSED_S2_QH; }
-
 hipError_t fused_s2_launch(const FusedArgs& a, int fmt, bool exact, hipStream_t stream) {
-#define FSR1_LAUNCH_E(F) return exact ? fused_s2_launch_one<F, true, FSR1_FUSED_S2_QH>(a, stream) : fused_s2_launch_one<F, false, FSR1_FUSED_S2_QH>(a, stream)
+#define FSR1_LAUNCH_E(F)                                                                                                         \
+  return a.run_steps > 1 ? (exact ? fused_s2_launch_one<F, true, true>(a, stream) : fused_s2_launch_one<F, false, true>(a, stream)) \
+                         : (exact ? fused_s2_launch_one<F, true, false>(a, stream) : fused_s2_launch_one<F, false, false>(a, stream))
   switch (fmt) {
     case FSR1_FORMAT_RGBA16F: FSR1_LAUNCH_E(FSR1_FORMAT_RGBA16F);
     case FSR1_FORMAT_RGBA32F: FSR1_LAUNCH_E(FSR1_FORMAT_RGBA32F);

@@ -561,7 +561,7 @@ def test_output_store_policy_does_not_change_pixels(fsr):
 
 @pytest.mark.parametrize("shape", [(31, 7), (32, 8), (30, 6), (31, 8), (63, 15), (62, 14), (1, 1), (2, 3), (100, 50), (125, 29)], ids=lambda s: "%dx%d" % s)
 def test_fused_exact_2x_quad_form(fsr, shape):
-    """fsr1_fused_s2.hip (62 x 14 output tiles, quads of the 64 x 16 apron tile, DPP-only RCAS neighbours) against the generic
+    """fsr1_fused_s2.hip (62-pixel columns walked in 16-row steps, a quad of the step's 64 x 16 EASU pixels per lane, DPP-only RCAS neighbours) against the generic
     fused kernel (FSR1_FLAG_NO_FAST_PATHS) and the two dispatches, at sizes on and around its tile boundaries, for every storage
     format, both arithmetics, the RCAS options, batches and padded rows: bit-identical."""
     iw, ih = shape
@@ -592,3 +592,35 @@ def test_fused_exact_2x_quad_form(fsr, shape):
             raw = {torch.float16: torch.int16, torch.float32: torch.int32, torch.uint8: torch.uint8}[dt]
             assert torch.equal(outs[0].view(raw), outs[1].view(raw)), "quad form != generic fused (%s, flags %d)" % (dt, flags)
             assert torch.equal(outs[0].view(raw), two.view(raw)), "quad form != two dispatches (%s, flags %d)" % (dt, flags)
+
+
+@pytest.mark.parametrize("steps", [1, 2, 3, 4, 5, 9, 11])
+@pytest.mark.parametrize("shape", [(97, 160), (31, 75), (64, 40), (70, 9)], ids=lambda s: "%dx%d" % s)
+def test_fused_exact_2x_run_steps(fsr, monkeypatch, shape, steps):
+    """The exact-2x fused kernel walks down its 62-pixel column in `steps` steps of 16 EASU rows, carrying the last two rows of a
+    step to the next in an 18-row LDS ring (fsr1_fused_s2.hip).  The host picks `steps` from the launch's size; whatever it is —
+    forced here through FSR1_FUSED_S2_STEPS, 9 steps take the ring through every one of its positions — the image is the same,
+    bit for bit, as the two dispatches', for whole images, batches and row bands."""
+    iw, ih = shape
+    ow, oh = 2 * iw, 2 * ih
+    n = 2
+    src = dev(np.stack([frames.synthetic_frame(iw, ih, k=40 + f, dtype=np.float16) for f in range(n)]))
+    for flags in (0, fsr.FLAG_MATH_EXACT | fsr.FLAG_RCAS_DENOISE):
+        mid = torch.zeros(n, oh, ow, 4, dtype=torch.float16, device="cuda")
+        two = torch.zeros_like(mid)
+        fsr.easu(src, mid, flags=flags & fsr.FLAG_MATH_EXACT)
+        fsr.rcas(mid, two, sharpness=0.3, flags=flags)
+        monkeypatch.setenv("FSR1_FUSED_S2_STEPS", str(steps))
+        big_out = torch.full((n, oh + 1, ow + 5, 4), 7, dtype=torch.float16, device="cuda")
+        dst = big_out[:, :oh, :ow]
+        fsr.easu_rcas_fused(src, dst, sharpness=0.3, flags=flags)
+        torch.cuda.synchronize()
+        assert bool((big_out[:, oh:] == 7).all()) and bool((big_out[:, :, ow:] == 7).all()), "wrote outside the output view"
+        assert torch.equal(dst.view(torch.int16), two.view(torch.int16)), "steps %d != two dispatches (flags %d)" % (steps, flags)
+        band = torch.full_like(two[0], -1.0)
+        cuts = [0, (oh // 3) & ~1, (2 * oh // 3) & ~1, oh]
+        for y0, y1 in zip(cuts, cuts[1:]):
+            if y1 > y0:
+                fsr.upscale_band(src[0], band[y0:y1], (ow, oh), (y0, y1), sharpness=0.3, flags=flags, fused=True)
+        assert torch.equal(band.view(torch.int16), two[0].view(torch.int16)), "bands at steps %d != two dispatches (flags %d)" % (steps, flags)
+        monkeypatch.delenv("FSR1_FUSED_S2_STEPS")

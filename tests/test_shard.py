@@ -122,3 +122,24 @@ def test_bench_two_gpus_over_rccl():
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["value"] > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("style", ["bare", "torchrun"])
+def test_bench_rccl_group_at_one_rank(style):
+    """--collective always: the RCCL communicator, barrier, all-reduce and all-gather of the N-rank path, run on the one GPU a box
+    has (world size 1) — the part of the multi-GPU path that is not index arithmetic, exercised on hardware."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    tail = [os.path.join(ROOT, "bench.py"), "--gpus", "1", "--collective", "always", "--steps", "50", "--warmup", "10", "--no-cpu-baseline", "--no-also",
+            "--no-cold-rcas", "--workload", "540p_to_1080p"]
+    cmd = [sys.executable] + tail if style == "bare" else \
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", "29519"] + tail
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["config"]["world_size_seen"] == 1 and line["config"]["collective_backend"].startswith("rccl")
+    assert line["value"] > 0 and len(line["per_rank_seconds"]) == 1

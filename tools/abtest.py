@@ -66,7 +66,7 @@ def child(args):
             return timer.elapsed_ms() / n
 
         n = max(10, int(args.launches / max(1, frames)))
-        row = {"lib": os.path.basename(os.environ.get("FSR1_HIP_LIB", "default")) + ("@" + os.environ["FSR1_AB_FLAGS"] if os.environ.get("FSR1_AB_FLAGS") else ""),
+        row = {"lib": os.path.basename(os.environ.get("FSR1_HIP_LIB", "default")) + ("@" + os.environ["FSR1_AB_FLAGS"] if os.environ.get("FSR1_AB_FLAGS") else "") + os.environ.get("FSR1_AB_TAG", ""),
                "workload": wl, "math": args.math}
         for name, fn in (("easu", easu), ("rcas", rcas), ("rcas_cold", rcas_cold), ("pair", pair), ("fused", fused)):
             if name in args.kernels.split(","):
@@ -95,6 +95,12 @@ def main():
         for lib in libs:
             env = dict(os.environ)
             env.pop("FSR1_AB_FLAGS", None)
+            env.pop("FSR1_AB_TAG", None)
+            while "%" in lib:  # `path%NAME=VALUE`: the variant runs with that environment variable (e.g. %FSR1_FUSED_S2_STEPS=5)
+                lib, kv = lib.rsplit("%", 1)
+                k, v = kv.split("=", 1)
+                env[k] = v
+                env["FSR1_AB_TAG"] = env.get("FSR1_AB_TAG", "") + "%" + kv
             if "@" in lib:  # `path@flags`: the library (empty = the tree's) with extra dispatch flag bits, e.g. @0x10 = FSR1_FLAG_MATH_EXACT
                 lib, env["FSR1_AB_FLAGS"] = lib.split("@", 1)
             if lib:
