@@ -9,6 +9,7 @@ NOTE="Round 2, BASELINE configs[0] shape: fp32 FsrEasuF, EASU only, RGBA32F stor
 NOTE="Round 2, 1.5x single frame" tools/gpu_profile.sh ${R}_1440p_to_4k_two-pass --workload 1440p_to_4k
 STEPS=100 NOTE="Round 2, BASELINE configs[2] per-GPU shard (8 frames per launch)" tools/gpu_profile.sh ${R}_1440p_to_4k_x8_two-pass --workload 1440p_to_4k_x8
 STEPS=40 PMC_STEPS=6 NOTE="Round 2, BASELINE configs[4] per-GPU shard (16 frames per launch)" tools/gpu_profile.sh ${R}_4k_to_8k_x16_two-pass --workload 4k_to_8k_x16
+STEPS=40 PMC_STEPS=6 NOTE="Round 2, BASELINE configs[4] per-GPU shard as ONE fused launch (what auto runs at exactly 2x)" tools/gpu_profile.sh ${R}_4k_to_8k_x16_fused --workload 4k_to_8k_x16 --pipeline fused
 python bench.py > gpurun_out/${R}_bench_default.json 2> gpurun_out/${R}_bench_default.err
 tail -c 600 gpurun_out/${R}_bench_default.json
 ls -la gpurun_out/profiles | head -40
