@@ -37,7 +37,10 @@ template <> struct RcasPair<FSR1_FORMAT_R10G10B10A2_UNORM> { typedef uint32_t T 
 // UP: the strip is walked from its last row to its first (interior strips only).  Vertically adjacent strips walk in
 // opposite directions, so the two apron rows they share are read by both at the same end of their lives — close in
 // time, the second reader from L2 — instead of ~a kernel duration apart.
-template <int FMT, bool EXACT, bool OPTS, bool INTERIOR, bool COLOR, int FOUT, int RING, bool UP = false>
+// XEDGE (with INTERIOR): the strip's own 128 columns and every row it reads are inside the image, but it is the image's first
+// and / or last wave-column: the apron column of lane 0 and / or lane 63 is outside, i.e. 0 (FSR_Pass.hlsl:45,61).  The interior
+// body with that one texel replaced, instead of the fully predicated one (2 of 30 wave-columns at 3840 pixels).
+template <int FMT, bool EXACT, bool OPTS, bool INTERIOR, bool COLOR, int FOUT, int RING, bool UP = false, bool XEDGE = false>
 __device__ __forceinline__ void rcas_strip(const RcasArgs& a, int frame, int x0, int y0, int lane) {
   typedef typename Pixel<FMT>::T texel_t;
   typedef typename RcasPair<FMT>::T pair_t;
@@ -52,11 +55,12 @@ __device__ __forceinline__ void rcas_strip(const RcasArgs& a, int frame, int x0,
   // apron column of lanes 0 / 63; the other lanes point at their own column so that the interior variant can load
   // unconditionally (no exec-masked branch: the compiler then counts vmcnt exactly and keeps the prefetch depth)
   const int hcol = lane == 0 ? x0 - 1 : (lane == 63 ? x0 + kRcasWaveCols : col);
-  const bool halo_ok = edge && (INTERIOR || (hcol >= 0 && hcol < W));
+  const bool halo_ok = edge && ((INTERIOR && !XEDGE) || (hcol >= 0 && hcol < W));
+  const bool halo_out = XEDGE && edge && !halo_ok;  // (an outside apron texel is never addressed: its lane re-reads column 0 / W - 1)
   // a row's address = wave-uniform 64-bit row base (scalar arithmetic) + a 32-bit lane offset: no 64-bit vector arithmetic
   const char* const in_frame = a.in.base + (long long)frame * a.in.frame_stride;
   char* const out_frame = a.out.base + (long long)frame * a.out.frame_stride;
-  const uint32_t off = (uint32_t)col * (uint32_t)sizeof(texel_t), hoff = (uint32_t)max(hcol, 0) * (uint32_t)sizeof(texel_t);
+  const uint32_t off = (uint32_t)col * (uint32_t)sizeof(texel_t), hoff = (uint32_t)min(max(hcol, 0), W - 1) * (uint32_t)sizeof(texel_t);
   const uint32_t ooff = (uint32_t)col * (uint32_t)sizeof(out_t);
   // keeps the zero-extension of a lane offset next to its use, where instruction selection can fold it into the
   // `global_load / global_store v_off, s[base]` addressing form (hoisted out of the row loop it becomes a 64-bit add per access)
@@ -80,6 +84,9 @@ __device__ __forceinline__ void rcas_strip(const RcasArgs& a, int frame, int x0,
 #else
       r.halo = *reinterpret_cast<const texel_t*>(in_frame + (long long)y * a.in.pitch + zext(hoff));
 #endif
+      if constexpr (XEDGE) {
+        if (halo_out) r.halo = Pixel<FMT>::zero();
+      }
     } else {
       r.p0 = Pixel<FMT>::zero();
       r.p1 = Pixel<FMT>::zero();
@@ -176,13 +183,15 @@ __global__ void __launch_bounds__(kRcasThreads) rcas_kernel(const RcasArgs a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int x0 = tx * kRcasCols + wave * kRcasWaveCols, y0 = ty * a.rows;
   if (x0 >= a.in.width) return;  // whole wave outside (no barriers in this kernel)
-  const bool interior = x0 >= 1 && x0 + kRcasWaveCols + 1 <= a.in.width && y0 >= 1 - a.rows_above && y0 + a.rows + 1 <= a.in.height + a.rows_below &&
-                        y0 + a.rows <= a.in.height;  // (the interior body stores every row of the strip)
+  const bool interior_y = y0 >= 1 - a.rows_above && y0 + a.rows + 1 <= a.in.height + a.rows_below &&
+                          y0 + a.rows <= a.in.height;  // (the interior body stores every row of the strip)
+  const bool interior = interior_y && x0 >= 1 && x0 + kRcasWaveCols + 1 <= a.in.width;
 #ifdef FSR1_RCAS_ALTERNATE
   if (interior && (ty & 1)) rcas_strip<FMT, EXACT, OPTS, true, COLOR, FOUT, RING, true>(a, frame, x0, y0, lane);
   else
 #endif
   if (interior) rcas_strip<FMT, EXACT, OPTS, true, COLOR, FOUT, RING>(a, frame, x0, y0, lane);
+  else if (interior_y && x0 + kRcasWaveCols <= a.in.width) rcas_strip<FMT, EXACT, OPTS, true, COLOR, FOUT, RING, false, true>(a, frame, x0, y0, lane);
   else rcas_strip<FMT, EXACT, OPTS, false, COLOR, FOUT, RING>(a, frame, x0, y0, lane);
 }
 
