@@ -135,8 +135,12 @@ def test_bench_rccl_group_at_one_rank(style):
     from conftest import ROOT
     tail = [os.path.join(ROOT, "bench.py"), "--gpus", "1", "--collective", "always", "--steps", "50", "--warmup", "10", "--no-cpu-baseline", "--no-also",
             "--no-cold-rcas", "--workload", "540p_to_1080p"]
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
     cmd = [sys.executable] + tail if style == "bare" else \
-        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", "29519"] + tail
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", str(port)] + tail
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
