@@ -1,0 +1,59 @@
+"""Register budgets of the built gfx950 kernels, read from the code objects inside libfsr1_hip.so (tools/kernel_meta.py) — no GPU.
+
+The kernels' speed rests on how many waves a SIMD holds (MI355X: 512 VGPRs per lane and SIMD: <= 64 registers -> 8 waves,
+<= 72 -> 7, <= 80 -> 6), and a spilled register in a filter loop costs more than any of the tunings DESIGN.md records.  These are
+the budgets the measurements of DESIGN.md section 3 were taken at; a compiler or source change that moves one shows up here, before
+a GPU is involved."""
+import os
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+LIB = os.path.join(ROOT, "fidelityfx-fsr_amd", "libfsr1_hip.so")
+
+
+@pytest.fixture(scope="module")
+def meta():
+    if not os.path.exists(LIB):
+        pytest.skip("libfsr1_hip.so not built")
+    import kernel_meta
+    m = kernel_meta.kernel_meta(LIB)
+    assert len(m) > 100, "expected every kernel instantiation of the library"
+    return m
+
+
+def test_no_kernel_spills_or_uses_scratch(meta):
+    bad = {k: v for k, v in meta.items() if v["vgpr_spills"] or v["scratch_bytes"]}
+    assert not bad, bad
+
+
+@pytest.mark.parametrize("kernel,max_vgpr", [
+    # the headline's kernels: exact-2x EASU (row-pair form) at seven waves, RCAS with the 2-row ring at eight
+    ("fsr1::easu_kernel<0, false, false, 0, true, false, 0>", 72),
+    ("fsr1::rcas_kernel<0, false, false, false, 0, 2>", 64),
+    # EXACT exact-2x EASU with the quad's analyses shared: seven waves
+    ("fsr1::easu_kernel<0, true, false, 0, true, false, 0>", 72),
+    # generic EASU (pitched layout): eight waves
+    ("fsr1::easu_kernel<0, false, false, 0, false, false, 48>", 64),
+    # fused exact-2x launch, one-step and walking form: seven workgroups per CU is what their LDS admits
+    ("fsr1::fused_s2_kernel<0, false, false>", 72),
+    ("fsr1::fused_s2_kernel<0, false, true>", 72),
+    ("fsr1::fused_s2_kernel<0, true, true>", 72),
+    # packed fp16
+    ("fsr1::easu_h_kernel<true>", 64),
+    ("fsr1::rcas_h_kernel<false>", 64),
+])
+def test_occupancy_critical_kernels_keep_their_register_budget(meta, kernel, max_vgpr):
+    assert kernel in meta, "kernel instantiation not found: %s" % kernel
+    assert meta[kernel]["vgpr"] <= max_vgpr, (kernel, meta[kernel])
+
+
+def test_walking_fused_kernel_fits_seven_workgroups_of_sgprs(meta):
+    """256-thread workgroups are admitted per CU up to floor(800 / (ceil(sgpr / 16) * 16 + 16)) (MI355X_MICROARCH.md, residency):
+    seven workgroups need at most 96 SGPRs."""
+    for k, v in meta.items():
+        if k.startswith("fsr1::fused_s2_kernel<"):
+            assert 800 // ((v["sgpr"] + 15) // 16 * 16 + 16) >= 7, (k, v)
