@@ -85,6 +85,64 @@ def gather_seconds(seconds, device):
     return [float(t.item()) for t in out]
 
 
+def median(xs):
+    xs = sorted(float(x) for x in xs)
+    n = len(xs)
+    return xs[n // 2] if n % 2 else 0.5 * (xs[n // 2 - 1] + xs[n // 2])
+
+
+def reduce_regions(region_seconds, device):
+    """Elementwise MAX over ranks of the R region times (one counters-only collective): region r of the job took as long as its
+    slowest rank's region r."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return [float(t) for t in region_seconds]
+    m = torch.tensor([float(t) for t in region_seconds], dtype=torch.float64, device=device)
+    dist.all_reduce(m, op=dist.ReduceOp.MAX)
+    return [float(t) for t in m.tolist()]
+
+
+STOPWATCH_SLACK = 1.03
+
+
+def check_stopwatch(line):
+    """Self-consistency of a bench line (Weak 1): kernels that run back to back on one stream cannot take longer
+    than the step that contains them.  Checked: sum of kernels[*].avg_kernel_us <= 1.03 x ms_per_step for the two dispatches,
+    and also_measured.fused.avg_kernel_us <= 1.03 x its own ms_per_step.  On violation the line is marked
+    "stopwatch_suspect": true, says which inequality failed, and every figure derived from the suspect kernel times (`frac`,
+    `achieved`, `hbm_frac`, `valu_frac`, `read_only`, `valu`, `cold_input.frac`) is removed rather than printed wrong.
+    Returns the list of violations (empty = consistent)."""
+    bad = []
+    step_us = line.get("ms_per_step", 0.0) * 1e3
+    kern = line.get("kernels") or {}
+    total = sum(k.get("avg_kernel_us", 0.0) for k in kern.values())
+    if kern and step_us > 0 and total > STOPWATCH_SLACK * step_us:
+        bad.append("sum of kernels[*].avg_kernel_us = %.2f us > %.2f x ms_per_step = %.2f us" % (total, STOPWATCH_SLACK, step_us))
+    fused = (line.get("also_measured") or {}).get("fused") or {}
+    if "avg_kernel_us" in fused and fused.get("ms_per_step", 0) > 0 and fused["avg_kernel_us"] > STOPWATCH_SLACK * fused["ms_per_step"] * 1e3:
+        bad.append("also_measured.fused.avg_kernel_us = %.2f us > %.2f x its ms_per_step = %.2f us"
+                   % (fused["avg_kernel_us"], STOPWATCH_SLACK, fused["ms_per_step"] * 1e3))
+    if bad:
+        line["stopwatch_suspect"] = True
+        line["stopwatch_violations"] = bad
+
+        def strip(r):
+            for k in ("frac", "achieved", "read_only", "valu", "hbm_frac", "valu_frac"):
+                r.pop(k, None)
+            if isinstance(r.get("cold_input"), dict):
+                r["cold_input"].pop("frac", None)
+        if isinstance(line.get("roofline"), dict):
+            strip(line["roofline"])
+        for r in kern.values():
+            strip(r)
+        if fused:
+            strip(fused)
+    else:
+        line["stopwatch_suspect"] = False
+    return bad
+
+
 def free_port():
     import socket
     with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
@@ -116,25 +174,31 @@ def stub_main(args, world, rank):
         dist.init_process_group("gloo")
     device = torch.device("cpu")
     in_w, in_h, out_w, out_h, frames = WORKLOADS[args.workload]
-    for _ in range(args.warmup):
-        pass
-    if world > 1:
-        dist.barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        time.sleep(1e-3)
-    seconds = time.perf_counter() - t0
-    if world > 1:
-        dist.barrier()
-    total = reduce_counters(frames * args.steps, frames * args.steps * out_w * out_h, seconds, device)
-    per_rank = gather_seconds(seconds, device)
+    own = []
+    for _ in range(args.regions):  # the same R-region bracket as the real run: barrier, K steps, clock, barrier
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            time.sleep(1e-3)
+        own.append(time.perf_counter() - t0)
+        if world > 1:
+            dist.barrier()
+    regions = reduce_regions(own, device)
+    seconds = median(regions)
+    total = reduce_counters(frames * args.steps, frames * args.steps * out_w * out_h, median(own), device)
+    total["seconds"] = seconds
+    per_rank = gather_seconds(median(own), device)
     if rank == 0:
         print(json.dumps({"metric": "stub (no GPU work): plumbing of bench.py --gpus N", "value": round(total["pixels"] / total["seconds"] / 1e6, 1),
                           "unit": "Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                           "ms_per_step": round(total["seconds"] * 1e3 / args.steps, 5), "higher_is_better": True, "scaling": "weak",
                           "vs_baseline": None, "dtype": "none", "data": "stub",
                           "config": {"workload": args.workload, "launch": launch_style(), "collective_backend": "gloo" if world > 1 else None,
-                                     "world_size_seen": dist.get_world_size() if world > 1 else 1, "frames_total": total["frames"]},
+                                     "world_size_seen": dist.get_world_size() if world > 1 else 1, "frames_total": total["frames"],
+                                     "regions": args.regions,
+                                     "region_ms_per_step": {"median": round(seconds * 1e3 / args.steps, 5), "min": round(min(regions) * 1e3 / args.steps, 5),
+                                                            "max": round(max(regions) * 1e3 / args.steps, 5)}},
                           "per_rank_seconds": [round(t, 6) for t in per_rank]}), flush=True)
     if world > 1:
         dist.destroy_process_group()
@@ -219,6 +283,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--regions", type=int, default=7,
+                    help="timed regions of exactly --steps steps each (barrier + synchronize either side); the line reports the median region")
     ap.add_argument("--workload", default="1080p_to_4k", choices=sorted(WORKLOADS))
     ap.add_argument("--pipeline", default="two-pass", choices=["two-pass", "fused", "easu", "color"],
                     help="color: the stand-alone colour pass (needs --stages) on an output-sized image")
@@ -255,6 +321,8 @@ def main():
 
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
+    if args.regions < 1:
+        raise SystemExit("--regions must be >= 1")
     if os.environ.get("WORLD_SIZE", "1") == "1" and args.gpus > 1 and os.environ.get("FSR1_BENCH_SELF_LAUNCHED") != "1":
         # started like `--gpus 1` is: one bare python process.  Start the ranks ourselves, exactly as the other launch style does.
         raise SystemExit(self_launch(sys.argv[1:], args.gpus))
@@ -389,6 +457,21 @@ def main():
     for i in range(args.warmup):
         step(i)
     fence()
+
+    def timed(fn, k, first=0):
+        """R timed regions of EXACTLY k steps each, every one bracketed by barrier + synchronize on both sides (fence /
+        close).  Returns (the R region times as the MAX over ranks, this rank's own R times).  The line's `ms_per_step` and
+        `value` use the MEDIAN region: at the driver's K = 20 a region is 1.3 ms, and one such sample — at N = 8 the MAX over
+        eight ranks of one such sample — is decided by whichever rank's first launch was slowest."""
+        own = []
+        for r in range(args.regions):
+            fence()
+            t0 = time.perf_counter()
+            for i in range(k):
+                fn(first + r * k + i)
+            own.append(close() - t0)
+        return reduce_regions(own, coll_device), own
+
     if args.graph > 0:
         # K steps = K / graph replays of a hipGraph holding `graph` consecutive steps (ring slots 0 .. graph-1, ...)
         args.steps = max(args.graph, args.steps // args.graph * args.graph)
@@ -397,38 +480,92 @@ def main():
             for i in range(args.graph):
                 step(i)
         g.replay()
-        fence()
-        t0 = time.perf_counter()
-        for _ in range(args.steps // args.graph):
-            g.replay()
-        seconds = close() - t0
+        regions, own_regions = timed(lambda i: g.replay(), args.steps // args.graph)
     else:
-        t0 = time.perf_counter()
-        for i in range(args.steps):
-            step(args.warmup + i)
-        seconds = close() - t0
+        regions, own_regions = timed(step, args.steps, first=args.warmup)
+    seconds = median(regions)
 
-    total = reduce_counters(frames * args.steps, frames * args.steps * out_w * out_h, seconds, coll_device)
-    per_rank_seconds = gather_seconds(seconds, coll_device)
+    total = reduce_counters(frames * args.steps, frames * args.steps * out_w * out_h, median(own_regions), coll_device)
+    total["seconds"] = seconds  # median over regions of the max over ranks
+    per_rank_seconds = gather_seconds(median(own_regions), coll_device)
     value = total["pixels"] / total["seconds"] / 1e6
 
+    # ---- per-kernel durations with HIP events on the launch stream (C-ABI stopwatch) ----
+    # Taken right after the headline regions (same clocks, same buffers) and INDEPENDENT of --steps: after a ramp of the very
+    # kernel being timed (>= 20 launches and >= 30 ms, so that clocks and power state are the steady ones — an idle MI355X drops
+    # its clock within a millisecond, and round 3's 20-launch stopwatch read 1.2-1.4 x the rocprofv3 average for that reason),
+    # B blocks of n launches each between one pair of events; the figure is the MEDIAN block.
+    timer = fsr.Timer()
+
+    def kernel_ms(fn, blocks=5):
+        t_r, i = time.perf_counter(), 0
+        while i < 20 or time.perf_counter() - t_r < 0.03:
+            fn(i)
+            i += 1
+            if i % 64 == 0:
+                torch.cuda.synchronize()
+        torch.cuda.synchronize()
+        est = max((time.perf_counter() - t_r) / i, 1e-6)  # host-clocked seconds per launch of the ramp
+        n = max(20, min(200, int(0.25 / est)))              # 200 launches for a 4K frame; fewer for multi-millisecond batches
+        per = []
+        for _ in range(blocks):
+            timer.start()
+            for j in range(n):
+                fn(i + j)
+            timer.stop()
+            per.append(timer.elapsed_ms() / n)
+            i += n
+        return median(per), {"launches_per_block": n, "blocks": blocks, "min_us": round(min(per) * 1e3, 2), "max_us": round(max(per) * 1e3, 2)}
+
+    kern, kern_info = {}, {}
+    rcas_cold_ms = None
+
+    def stopwatch(name, fn):
+        kern[name], kern_info[name] = kernel_ms(fn)
+
+    if args.pipeline in ("two-pass", "easu"):
+        eflags = math_flags | (0 if args.pipeline == "two-pass" else fsr.FLAG_OUTPUT_STREAMING)
+        stopwatch("easu", lambda i: fsr.easu(srcs[i % ring], mid if args.pipeline == "two-pass" else dsts[i % ring], con=easu_con,
+                                             flags=eflags, stages=pre if args.pipeline == "two-pass" else stages))
+    if args.pipeline == "two-pass":
+        # as inside the pipeline: the input is the intermediary EASU left behind (for one 4K frame, in the Infinity Cache)
+        stopwatch("rcas", lambda i: fsr.rcas(mid, dsts[i % ring], con=rcas_con, flags=math_flags, stages=post))
+        if not args.stages and ring >= 4 and not args.no_cold_rcas:
+            # and on an image that comes from HBM: an output written ring/2 steps ago (non-temporal stores, > 512 MB of traffic since)
+            rcas_cold_ms = kernel_ms(lambda i: fsr.rcas(dsts[(i + ring // 2) % ring], dsts[i % ring], con=rcas_con, flags=math_flags))[0]
+    if args.pipeline == "fused":
+        stopwatch("fused", lambda i: fsr.easu_rcas_fused(srcs[i % ring], dsts[i % ring], easu_con=easu_con, rcas_con=rcas_con,
+                                                         flags=math_flags, stages=stages))
+    if args.pipeline == "color":
+        stopwatch("color", lambda i: fsr.color(srcs[i % ring], dsts[i % ring], stages, flags=math_flags))
+
     # The single-launch pipeline (BASELINE configs[3]) writes the very same image as the two dispatches
-    # (tests: fused == two-pass, bit for bit); the default run times it over the same K steps as well and reports it
-    # beside the headline, which stays the two-dispatch pipeline BASELINE's metric is quoted on.
+    # (tests: fused == two-pass, bit for bit); the default run times it over the same K steps (and R regions) as well and
+    # reports it beside the headline, which stays the two-dispatch pipeline BASELINE's metric is quoted on.
     also = None
+
+    def also_entry(fn, note, px_per_step=None):
+        for i in range(min(args.warmup, 50)):
+            fn(i)
+        reg, _ = timed(fn, args.steps)
+        sec = median(reg)
+        return {"value": round((px_per_step or frames * out_w * out_h) * args.steps * world / sec / 1e6, 1), "unit": "Mpix/s",
+                "ms_per_step": round(sec * 1e3 / args.steps, 5), "ms_per_step_min": round(min(reg) * 1e3 / args.steps, 5),
+                "ms_per_step_max": round(max(reg) * 1e3 / args.steps, 5), "note": note}
+
     if args.pipeline == "two-pass" and not args.stages and args.math != "h" and not args.no_also:
         def fused_step(i):
             fsr.easu_rcas_fused(srcs[i % ring], dsts[i % ring], easu_con=easu_con, rcas_con=rcas_con, flags=math_flags)
-        for i in range(min(args.warmup, 50)):
-            fused_step(i)
-        fence()
-        t0 = time.perf_counter()
-        for i in range(args.steps):
-            fused_step(i)
-        tf = reduce_counters(frames * args.steps, frames * args.steps * out_w * out_h, close() - t0, coll_device)
-        also = {"fused": {"value": round(tf["pixels"] / tf["seconds"] / 1e6, 1), "unit": "Mpix/s",
-                          "ms_per_step": round(tf["seconds"] * 1e3 / args.steps, 5),
-                          "note": "EASU->RCAS in one launch, output bit-identical to the two dispatches (BASELINE configs[3])"}}
+        also = {"fused": also_entry(fused_step, "EASU->RCAS in one launch, output bit-identical to the two dispatches (BASELINE configs[3])")}
+        # the single launch as a kernel: HIP-event time per launch, its algorithmic bytes (in + out) against the HBM line, and
+        # the PMC traffic / VALU count of its own committed profile when that was taken of the running sources
+        tf_ms, tf_info = kernel_ms(fused_step)
+        fpmc = pmc_traffic(fsr, args.workload, "fused", "fused", args.math, args.storage) if not args.no_fast_paths else (None, None, None, None)
+        also["fused"].update({"avg_kernel_us": round(tf_ms * 1e3, 2), "stopwatch": tf_info, "algorithmic_bytes": in_bytes + out_bytes,
+                              "hbm_frac": round((in_bytes + out_bytes) / (tf_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                              "traffic": fpmc[0], "traffic_source": fpmc[1]})
+        if fpmc[2]:
+            also["fused"]["valu_frac"] = round(fpmc[2] / (tf_ms * 1e-3) / 1e9 / VALU_PEAK_GINST, 4)
         if args.storage == "rgba16f" and args.math == "f":
             # the reference's shipping default (FsrEasuH / FsrRcasH, FSR_Pass.hlsl:81-87) on the same frames, same K steps
             hflags = fsr.FLAG_MATH_PACKED_FP16
@@ -436,13 +573,6 @@ def main():
             def h_step(i):
                 fsr.easu(srcs[i % ring], mid, con=easu_con, flags=hflags)
                 fsr.rcas(mid, dsts[i % ring], con=rcas_con, flags=hflags)
-            for i in range(min(args.warmup, 50)):
-                h_step(i)
-            fence()
-            t0 = time.perf_counter()
-            for i in range(args.steps):
-                h_step(i)
-            th = reduce_counters(frames * args.steps, frames * args.steps * out_w * out_h, close() - t0, coll_device)
             # and the bit-exact arithmetic (FSR1_FLAG_MATH_EXACT: the reference's operation order, no re-association): what
             # bit-identity with the CPU-evaluated FsrEasuF / FsrRcasF costs against the default (<= 1 ULP) arithmetic
             eflags_x = fsr.FLAG_MATH_EXACT
@@ -450,20 +580,13 @@ def main():
             def x_step(i):
                 fsr.easu(srcs[i % ring], mid, con=easu_con, flags=eflags_x)
                 fsr.rcas(mid, dsts[i % ring], con=rcas_con, flags=eflags_x)
-            for i in range(min(args.warmup, 50)):
-                x_step(i)
-            fence()
-            t0 = time.perf_counter()
-            for i in range(args.steps):
-                x_step(i)
-            tx = reduce_counters(frames * args.steps, frames * args.steps * out_w * out_h, close() - t0, coll_device)
-            also["exact_two_pass"] = {"value": round(tx["pixels"] / tx["seconds"] / 1e6, 1), "unit": "Mpix/s",
-                                      "ms_per_step": round(tx["seconds"] * 1e3 / args.steps, 5),
-                                      "note": "FSR1_FLAG_MATH_EXACT: bit-identical to the CPU-evaluated FsrEasuF + FsrRcasF (0 differing values on whole frames)"}
-            also["packed_fp16_two_pass"] = {"value": round(th["pixels"] / th["seconds"] / 1e6, 1), "unit": "Mpix/s",
-                                            "ms_per_step": round(th["seconds"] * 1e3 / args.steps, 5),
-                                            "note": "FsrEasuH + FsrRcasH (parity class H: bit-exact vs the reference's packed-fp16 path; "
-                                                    "v_pk_*_f16 issue at half rate on MI355X, DESIGN.md 3.4)"}
+            also["exact_two_pass"] = also_entry(x_step, "FSR1_FLAG_MATH_EXACT: bit-identical to the CPU-evaluated FsrEasuF + FsrRcasF (0 differing values on whole frames)")
+            also["packed_fp16_two_pass"] = also_entry(h_step, "FsrEasuH + FsrRcasH (parity class H: bit-exact vs the reference's packed-fp16 path; "
+                                                              "v_pk_*_f16 issue at half rate on MI355X, DESIGN.md 3.4)")
+
+            def hf_step(i):
+                fsr.easu_rcas_fused(srcs[i % ring], dsts[i % ring], easu_con=easu_con, rcas_con=rcas_con, flags=hflags)
+            also["packed_fp16_fused"] = also_entry(hf_step, "FsrEasuH -> FsrRcasH in one launch, bit-identical to the two H dispatches")
 
         if args.workload == "1080p_to_4k" and args.storage == "rgba16f" and args.math == "f" and not args.no_fast_paths:
             # BASELINE configs[2]'s shape on the same box and K steps (one 2560x1440 -> 3840x2160 frame per step, "Quality"
@@ -475,60 +598,9 @@ def main():
             def q_step(i):
                 fsr.easu(q_in[i % ring], mid, con=q_con, flags=math_flags)
                 fsr.rcas(mid, dsts[i % ring], con=rcas_con, flags=math_flags)
-            for i in range(min(args.warmup, 50)):
-                q_step(i)
-            fence()
-            t0 = time.perf_counter()
-            for i in range(args.steps):
-                q_step(i)
-            tq = reduce_counters(args.steps, args.steps * out_w * out_h, close() - t0, coll_device)
-            also["quality_1440p_to_4k_two_pass"] = {"value": round(tq["pixels"] / tq["seconds"] / 1e6, 1), "unit": "Mpix/s",
-                                                    "ms_per_step": round(tq["seconds"] * 1e3 / args.steps, 5),
-                                                    "note": "2560x1440 -> 3840x2160 (1.5x, BASELINE configs[2]'s shape), EASU + RCAS as two dispatches, generic kernels"}
+            also["quality_1440p_to_4k_two_pass"] = also_entry(q_step, "2560x1440 -> 3840x2160 (1.5x, BASELINE configs[2]'s shape), EASU + RCAS as two dispatches, generic kernels",
+                                                              px_per_step=out_w * out_h)
             del q_in
-
-    # ---- per-kernel durations with HIP events on the launch stream (C-ABI stopwatch) ----
-    timer = fsr.Timer()
-
-    def kernel_ms(fn, n):
-        for i in range(3):
-            fn(i)
-        torch.cuda.synchronize()
-        timer.start()
-        for i in range(n):
-            fn(i)
-        timer.stop()
-        return timer.elapsed_ms() / n
-
-    n_k = max(20, min(args.steps, 200))
-    kern = {}
-    rcas_cold_ms = None
-    if args.pipeline in ("two-pass", "easu"):
-        eflags = math_flags | (0 if args.pipeline == "two-pass" else fsr.FLAG_OUTPUT_STREAMING)
-        kern["easu"] = kernel_ms(lambda i: fsr.easu(srcs[i % ring], mid if args.pipeline == "two-pass" else dsts[i % ring], con=easu_con,
-                                                    flags=eflags, stages=pre if args.pipeline == "two-pass" else stages), n_k)
-    if args.pipeline == "two-pass":
-        # as inside the pipeline: the input is the intermediary EASU left behind (for one 4K frame, in the Infinity Cache)
-        kern["rcas"] = kernel_ms(lambda i: fsr.rcas(mid, dsts[i % ring], con=rcas_con, flags=math_flags, stages=post), n_k)
-        if not args.stages and ring >= 4 and not args.no_cold_rcas:
-            # and on an image that comes from HBM: an output written ring/2 steps ago (non-temporal stores, > 512 MB of traffic since)
-            rcas_cold_ms = kernel_ms(lambda i: fsr.rcas(dsts[(i + ring // 2) % ring], dsts[i % ring], con=rcas_con, flags=math_flags), n_k)
-    if args.pipeline == "fused":
-        kern["fused"] = kernel_ms(lambda i: fsr.easu_rcas_fused(srcs[i % ring], dsts[i % ring], easu_con=easu_con, rcas_con=rcas_con,
-                                                                flags=math_flags, stages=stages), n_k)
-    if args.pipeline == "color":
-        kern["color"] = kernel_ms(lambda i: fsr.color(srcs[i % ring], dsts[i % ring], stages, flags=math_flags), n_k)
-
-    if also and "fused" in also:
-        # the single launch as a kernel: HIP-event time per launch, its algorithmic bytes (in + out) against the HBM line, and
-        # the PMC traffic / VALU count of its own committed profile when that was taken of the running sources
-        tf_ms = kernel_ms(lambda i: fsr.easu_rcas_fused(srcs[i % ring], dsts[i % ring], easu_con=easu_con, rcas_con=rcas_con, flags=math_flags), n_k)
-        fpmc = pmc_traffic(fsr, args.workload, "fused", "fused", args.math, args.storage) if not args.no_fast_paths else (None, None, None, None)
-        also["fused"].update({"avg_kernel_us": round(tf_ms * 1e3, 2), "algorithmic_bytes": in_bytes + out_bytes,
-                              "hbm_frac": round((in_bytes + out_bytes) / (tf_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
-                              "traffic": fpmc[0], "traffic_source": fpmc[1]})
-        if fpmc[2]:
-            also["fused"]["valu_frac"] = round(fpmc[2] / (tf_ms * 1e-3) / 1e9 / VALU_PEAK_GINST, 4)
 
     # algorithmic HBM bytes per launch: EASU in+out, RCAS 2*out, fused in+out
     alg = {"easu": in_bytes + out_bytes, "rcas": 2 * out_bytes, "fused": in_bytes + out_bytes, "color": 2 * out_bytes}
@@ -543,7 +615,7 @@ def main():
              # this configuration, and only when that summary was taken of the kernel sources running now (source_hash)
              "traffic_kind": "profile-lookup" if pmc[0] is not None else None,
              "traffic_source": pmc[1], "algorithmic_bytes": alg[name],
-             "avg_kernel_us": round(kern[name] * 1e3, 2)}
+             "avg_kernel_us": round(kern[name] * 1e3, 2), "stopwatch": kern_info[name]}
         if name == "rcas":
             r["input"] = "the EASU->RCAS intermediary, one buffer reused by every step (Infinity-Cache resident for a single 4K frame), as inside the pipeline"
             if rcas_cold_ms:
@@ -583,9 +655,12 @@ def main():
                        "launch": launch_style(), "world_size_seen": dist.get_world_size() if grouped else 1,
                        "collective_backend": (("rccl (torch.distributed 'nccl')" if args.backend == "nccl" else "gloo") if grouped else None),
                        "devices_visible": n_dev, "oversubscribed": bool(world > n_dev),
-                       "k_dependence": "the timed region is host-clocked around K steps: at K = 20 (1.3 ms) the first launch's latency and the closing "
-                                       "synchronize are 1-6 % of it (round 3, one box: 124.4 Gpix/s at K = 20, 125.9 at K = 2000; round 2's driver run: 117.7 at "
-                                       "K = 20 against 122-126 at K >= 300 on the same kernels)",
+                       "regions": args.regions,
+                       "region_ms_per_step": {"median": round(median(regions) * 1e3 / args.steps, 5), "min": round(min(regions) * 1e3 / args.steps, 5),
+                                              "max": round(max(regions) * 1e3 / args.steps, 5)},
+                       "timing": "R = `regions` timed regions of exactly K = `steps` steps, each bracketed by barrier + synchronize on both sides and "
+                                 "reduced with MAX over ranks; value / ms_per_step are the MEDIAN region (a K = 20 region of 4K frames is 1.3 ms: the first "
+                                 "launch's latency and the closing synchronize are 1-6 % of it, so single regions scatter by that much)",
                        "pipeline": args.pipeline, "storage": args.storage, "color_stages": args.stages, "hip_graph_steps": args.graph, "rcas_sharpness_stops": 0.25,
                        "parallelism": "independent frames per GPU, counters-only collective"},
             "per_rank_seconds": [round(t, 6) for t in per_rank_seconds],
@@ -596,6 +671,7 @@ def main():
         }
         if also:
             line["also_measured"] = also
+        check_stopwatch(line)  # sum of kernel times <= the step that contains them, or the line says "stopwatch_suspect"
         if world == 1 and not args.no_cpu_baseline and args.pipeline != "color" and not args.stages:
             line["cpu_baseline"] = cpu_baseline(fsr, in_w, in_h, out_w, out_h)
         print(json.dumps(line), flush=True)

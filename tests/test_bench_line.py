@@ -1,0 +1,54 @@
+"""bench.py's self-consistency check of its own line (no GPU): kernels that run back to back on one stream cannot take longer
+than the step that contains them.  Round 3's driver line violated exactly that (a 20-launch stopwatch on a GPU that had just
+idled read EASU 54.95 us + RCAS 30.2 us inside a 65.17 us step, fused 77.82 us inside a 59.53 us step) and printed a roofline
+fraction that followed from neither the committed rocprofv3 summaries nor its own headline."""
+import copy
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+
+def _line(easu_us, rcas_us, step_ms, fused_us, fused_step_ms):
+    roof = lambda name, us, alg: {"kernel": name, "bound": "hbm", "achieved": alg / us / 1e3, "peak": 8000.0, "unit": "GB/s",  # noqa: E731
+                                  "frac": alg / us / 1e3 / 8000.0, "avg_kernel_us": us, "algorithmic_bytes": alg,
+                                  "read_only": {"frac": 0.05}, "valu": {"frac": 0.6}}
+    k = {"easu": roof("easu", easu_us, 82944000), "rcas": roof("rcas", rcas_us, 132710400)}
+    k["rcas"]["cold_input"] = {"avg_kernel_us": rcas_us * 1.3, "frac": 0.5}
+    return {"ms_per_step": step_ms, "roofline": copy.deepcopy(k["easu"]), "kernels": k,
+            "also_measured": {"fused": {"ms_per_step": fused_step_ms, "avg_kernel_us": fused_us, "hbm_frac": 0.17, "valu_frac": 0.6}}}
+
+
+def test_round3_driver_line_is_flagged():
+    line = _line(54.95, 30.2, 0.06517, 77.82, 0.05953)  # BENCH_r03.json's figures
+    bad = bench.check_stopwatch(line)
+    assert len(bad) == 2 and line["stopwatch_suspect"] is True and len(line["stopwatch_violations"]) == 2
+    # nothing derived from the suspect kernel times is printed
+    assert "frac" not in line["roofline"] and "achieved" not in line["roofline"] and "read_only" not in line["roofline"]
+    for r in line["kernels"].values():
+        assert "frac" not in r and "valu" not in r
+    assert "frac" not in line["kernels"]["rcas"]["cold_input"]
+    assert "hbm_frac" not in line["also_measured"]["fused"] and "valu_frac" not in line["also_measured"]["fused"]
+    # the raw measurements stay, so that the reader sees what was wrong
+    assert line["kernels"]["easu"]["avg_kernel_us"] == 54.95 and line["also_measured"]["fused"]["avg_kernel_us"] == 77.82
+
+
+def test_consistent_line_passes_untouched():
+    line = _line(40.12, 24.68, 0.06517, 59.87, 0.05953)  # profiles/r03_*'s rocprofv3 averages inside the same steps
+    before = copy.deepcopy(line)
+    assert bench.check_stopwatch(line) == [] and line["stopwatch_suspect"] is False
+    del line["stopwatch_suspect"]
+    assert line == before
+
+
+def test_only_the_fused_figure_suspect():
+    line = _line(40.12, 24.68, 0.06517, 77.82, 0.05953)
+    bad = bench.check_stopwatch(line)
+    assert len(bad) == 1 and "fused" in bad[0] and line["stopwatch_suspect"] is True
+
+
+def test_median():
+    assert bench.median([3, 1, 2]) == 2 and bench.median([4, 1, 2, 3]) == 2.5 and bench.median([7]) == 7
+    assert bench.reduce_regions([0.5, 0.25], None) == [0.5, 0.25]  # identity without a process group

@@ -60,13 +60,14 @@ def _bench_line(cmd, env=None, timeout=600):
     return json.loads(lines[0])
 
 
-@pytest.mark.parametrize("n", [1, 2])
+@pytest.mark.parametrize("n", [1, 2, 8])
 @pytest.mark.parametrize("style", ["bare", "torchrun"])
 def test_bench_launch_styles_stub(n, style):
     """Both ways the driver may start `bench.py --gpus N` — a bare `python bench.py --gpus N` (bench.py starts the ranks
     itself) and `python -m torch.distributed.run ... bench.py --gpus N` — give one JSON line with the contract's fields,
     the world size the process group saw and every rank's seconds.  --stub: rendezvous, barriers and the counters-only
-    collectives over gloo with 1 ms of sleep per step instead of GPU work, so the plumbing runs on the CPU-only builder."""
+    collectives over gloo with 1 ms of sleep per step instead of GPU work, so the plumbing runs on the CPU-only builder.
+    n = 8 is the driver's largest SCALE point (one node): eight ranks, eight per_rank_seconds, world_size_seen == 8."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "FSR1_BENCH_SELF_LAUNCHED")}
     tail = [os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "6", "--warmup", "2", "--stub"]
     if style == "bare":
@@ -80,7 +81,12 @@ def test_bench_launch_styles_stub(n, style):
     assert line["n_gpus"] == n and line["steps"] == 6 and line["warmup"] == 2 and line["scaling"] == "weak" and line["data"] == "stub"
     assert line["config"]["world_size_seen"] == n and len(line["per_rank_seconds"]) == n
     assert line["config"]["frames_total"] == 6 * n  # weak scaling: every rank did its own K steps
-    assert abs(line["ms_per_step"] - max(line["per_rank_seconds"]) * 1e3 / 6) < 1e-3  # MAX over ranks
+    # R regions of exactly K steps; ms_per_step = median over regions of the MAX over ranks, per_rank_seconds = each rank's own median
+    reg = line["config"]["region_ms_per_step"]
+    assert line["config"]["regions"] == 7 and reg["min"] <= reg["median"] <= reg["max"] and reg["median"] == line["ms_per_step"]
+    assert reg["min"] >= 1.0  # a step sleeps 1 ms
+    assert line["ms_per_step"] >= min(line["per_rank_seconds"]) * 1e3 / 6 - 1e-3
+    assert abs(line["ms_per_step"] - max(line["per_rank_seconds"]) * 1e3 / 6) < 0.25 * line["ms_per_step"]
     if n > 1:
         assert ("self-launched" in line["config"]["launch"]) == (style == "bare")
 
