@@ -78,6 +78,7 @@ SYMBOLS = {
     "fsr1_version": (ctypes.c_int, []),
     "fsr1_device_count": (ctypes.c_int, []),
     "fsr1_selftest": (ctypes.c_int, [_U32P]),
+    "fsr1_debug_fused_run_steps": (None, [ctypes.c_int32]),
     "fsr1_timer_create": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p)]),
     "fsr1_timer_start": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     "fsr1_timer_stop": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
@@ -134,6 +135,9 @@ def load():
             fn.restype = res
             fn.argtypes = args
         _lib = lib
+        forced = os.environ.get("FSR1_FUSED_S2_STEPS")  # tuning runs (tools/abtest.py `lib%FSR1_FUSED_S2_STEPS=n`): the library itself reads no environment
+        if forced:
+            lib.fsr1_debug_fused_run_steps(int(forced))
     return _lib
 
 

@@ -224,7 +224,9 @@ def easu_rcas_fused_band(src, dst_band, easu_con, rcas_con=None, sharpness=0.25,
 def upscale_band(src, dst_band, out_size, band, mid=None, sharpness=0.25, flags=0, stream=None, fused=False):
     """EASU + RCAS for output rows [band[0], band[1]) of an `out_size` = (width, height) upscale of `src`, written to `dst_band`
     (band[1] - band[0] rows): what one GPU does when a single frame is split into row bands.  `mid` (optional)
-    is a scratch tensor of at least band rows + 3; fused=True takes the single launch (no intermediary); returns dst_band."""
+    is a scratch tensor (out_size[0] pixels wide, dst_band's dtype and device) of at least band rows + 3 — one EASU row either side
+    of the band plus one more so that the intermediary can start on an even row; a smaller or mismatched one is refused (it is
+    never silently truncated).  fused=True takes the single launch (no intermediary); returns dst_band."""
     import torch
     ow, oh = out_size
     y0, y1 = band
@@ -238,6 +240,13 @@ def upscale_band(src, dst_band, out_size, band, mid=None, sharpness=0.25, flags=
     m0, m1 = max(y0 - 1, 0) & ~1, min(y1 + 1, oh)
     if mid is None:
         mid = torch.empty(m1 - m0, ow, 4, dtype=dst_band.dtype, device=dst_band.device)
+    else:
+        if mid.dim() != 3 or mid.shape[0] < m1 - m0 or mid.shape[1] != ow or mid.shape[2] != 4:
+            raise Fsr1Error("upscale_band: the intermediary must be (>= %d, %d, 4) — output rows [%d, %d), i.e. band rows + up to 3 — got %s"
+                            % (m1 - m0, ow, m0, m1, tuple(mid.shape)))
+        if mid.dtype != dst_band.dtype or mid.device != dst_band.device:
+            raise Fsr1Error("upscale_band: the intermediary must have the band's dtype and device (%s on %s), got %s on %s"
+                            % (dst_band.dtype, dst_band.device, mid.dtype, mid.device))
     mid = mid[:m1 - m0]
     # FSR_Filter.cpp:107: EASU's Sample.x is 0 when RCAS follows — the HDR square, RCAS options and the store policy of the
     # final image belong to the RCAS dispatch only (the fused launch squares once, and so must the two dispatches)

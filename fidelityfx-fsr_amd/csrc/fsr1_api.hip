@@ -22,7 +22,8 @@ hipError_t fused_h_launch(const FusedArgs& a, hipStream_t stream);
 hipError_t fused_s2_launch(const FusedArgs& a, int fmt, bool exact, hipStream_t stream);
 size_t fused_s2_lds_bytes(int fmt);
 void fused_s2_geometry(int width, int height, int steps, int* tiles_x, int* tiles_y);
-int fused_s2_run_steps(int width, int height, int frames);
+int fused_s2_run_steps(int width, int height, int frames, int cus);
+void fused_s2_force_steps(int steps);
 size_t fused_h_lds_bytes(int fp_w, int fp_h);
 hipError_t easu_h_launch(const EasuArgs& a, bool s2, hipStream_t stream);
 hipError_t easu_color_launch(const EasuArgs& a, int fin, int fout, bool exact, hipStream_t stream);
@@ -231,6 +232,22 @@ static int check_color(const fsr1_color_stages* st, const char* who, ColorArgs* 
 // Format pairs the colour variants of the EASU / RCAS / fused kernels are built for.
 static bool color_format_pair_ok(int fin, int fout) {
   return fin == fout || (fin == FSR1_FORMAT_RGBA16F && (fout == FSR1_FORMAT_RGBA8_UNORM || fout == FSR1_FORMAT_R10G10B10A2_UNORM));
+}
+
+// Compute units of the current device (256 on MI355X; 304 on an MI300X, 32 in CPX partitions), read once per device: launch
+// rules that count residencies (fsr1_fused_s2.hip) scale with it instead of assuming the part they were measured on.
+static int device_cus() {
+  constexpr int kDevices = 64;
+  static std::atomic<int> cache[kDevices];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 256;
+  if (dev >= 0 && dev < kDevices) {
+    if (const int c = cache[dev].load(std::memory_order_relaxed); c > 0) return c;
+  }
+  int cus = 0;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) return 256;
+  if (dev >= 0 && dev < kDevices) cache[dev].store(cus, std::memory_order_relaxed);
+  return cus;
 }
 
 // fsr1_params.fused = 2 ("auto"), on round-2 measurements: at exactly 2x the quad form of the fused
@@ -488,7 +505,7 @@ static int fused_dispatch_impl(const fsr1_image* in, const fsr1_image* out, cons
   const bool s2 = easu_con[0] == 0x3f000000u && easu_con[1] == 0x3f000000u && easu_con[2] == 0xbe800000u && easu_con[3] == 0xbe800000u &&
                   !(flags & FSR1_FLAG_NO_FAST_PATHS) && !packed && !a.color.stages && !(origin_y & 1) &&
                   fused_s2_lds_bytes(in->format) <= 160 * 1024;
-  a.run_steps = s2 ? fused_s2_run_steps(out->width, out->height, out->frames) : 0;
+  a.run_steps = s2 ? fused_s2_run_steps(out->width, out->height, out->frames, device_cus()) : 0;
   if (s2) fused_s2_geometry(out->width, out->height, a.run_steps, &a.tiles_x, &a.tiles_y);
   if ((rc = check_grid("fused", a.tiles_x, a.tiles_y, a.frames))) return rc;
   a.flags = resolve_output_policy(flags, true);
@@ -540,33 +557,73 @@ int fsr1_upscale(const fsr1_image* in, const fsr1_image* intermediary, const fsr
   return fsr1_upscale_ex(in, intermediary, out, p, nullptr, stream);
 }
 
+// Argument validation and the pipeline decision of fsr1_upscale_ex, shared with fsr1_upscale_plan so that the plan is by
+// construction what the call does (and refuses what the call refuses).  `in` / `out` are checked as descriptors only (extents,
+// formats, frame counts): the plan is asked without device pointers.
+struct UpscalePlan {
+  int pipeline;  // 0 = EASU + RCAS as two dispatches, 1 = the fused launch, 2 = EASU only
+  uint32_t easu_con[16], rcas_con[4];
+  uint32_t math, rcas_flags, out_policy;
+};
+
+static int upscale_decide(const char* who, const fsr1_image* in, bool have_intermediary, const fsr1_image* out, const fsr1_params* p,
+                          bool have_stages, UpscalePlan* plan) {
+  if (!in || !out || !p) return fail(FSR1_ERR_INVALID_ARGUMENT, "%s: null argument", who);
+  for (const fsr1_image* im : {in, out}) {
+    if (im->width <= 0 || im->height <= 0 || im->frames <= 0)
+      return fail(FSR1_ERR_INVALID_ARGUMENT, "%s: bad %s extent %dx%dx%d", who, im == in ? "input" : "output", im->width, im->height, im->frames);
+    if (im->format < FSR1_FORMAT_RGBA16F || im->format > FSR1_FORMAT_R10G10B10A2_UNORM)
+      return fail(FSR1_ERR_UNSUPPORTED, "%s: unsupported %s format %d", who, im == in ? "input" : "output", im->format);
+  }
+  if (in->frames != out->frames) return fail(FSR1_ERR_INVALID_ARGUMENT, "%s: frame counts differ (%d vs %d)", who, in->frames, out->frames);
+  if (!(p->render_width >= 1.0f) || !(p->render_height >= 1.0f) || p->render_width > (float)in->width || p->render_height > (float)in->height)
+    return fail(FSR1_ERR_INVALID_ARGUMENT, "%s: render size %gx%g must lie within the input image %dx%d", who, (double)p->render_width,
+                (double)p->render_height, in->width, in->height);
+  int rc;
+  if ((rc = check_flags(p->flags))) return rc;
+  plan->math = p->flags & (FSR1_FLAG_MATH_EXACT | FSR1_FLAG_MATH_PACKED_FP16 | FSR1_FLAG_NO_FAST_PATHS);
+  const uint32_t rcas_opts = p->flags & (FSR1_FLAG_RCAS_DENOISE | FSR1_FLAG_RCAS_PASSTHROUGH_ALPHA);
+  plan->out_policy = p->flags & (FSR1_FLAG_OUTPUT_STREAMING | FSR1_FLAG_OUTPUT_CACHED);  // of the pass that writes `out`
+  if (p->flags & ~(plan->math | rcas_opts | plan->out_policy))
+    return fail(FSR1_ERR_INVALID_ARGUMENT, "%s: params.flags may only hold MATH_*, RCAS_* and OUTPUT_* bits", who);
+  if ((plan->math & FSR1_FLAG_MATH_PACKED_FP16) && (in->format != FSR1_FORMAT_RGBA16F || out->format != FSR1_FORMAT_RGBA16F || have_stages))
+    return fail(FSR1_ERR_UNSUPPORTED, "%s: packed-fp16 math needs RGBA16F images and runs without colour stages", who);
+  // :106 — viewport == input resource size == (renderWidth, renderHeight); output = display size
+  FsrEasuCon(plan->easu_con, plan->easu_con + 4, plan->easu_con + 8, plan->easu_con + 12, p->render_width, p->render_height, p->render_width,
+             p->render_height, (float)out->width, (float)out->height);
+  float sx, sy, bx, by;
+  memcpy(&sx, &plan->easu_con[0], 4);
+  memcpy(&sy, &plan->easu_con[1], 4);
+  memcpy(&bx, &plan->easu_con[2], 4);
+  memcpy(&by, &plan->easu_con[3], 4);
+  const int fp_w = footprint_extent(out->width, kTileW, 0, sx, bx), fp_h = footprint_extent(out->height, kTileH, 0, sy, by);
+  if (fp_w < 0 || fp_h < 0) return fail(FSR1_ERR_INVALID_ARGUMENT, "%s: scale constants con0.xy = (%g, %g) are not usable", who, sx, sy);
+  if (!p->use_rcas) {
+    plan->pipeline = 2;
+    return FSR1_OK;
+  }
+  FsrRcasCon(plan->rcas_con, p->rcas_attenuation);  // :124
+  plan->rcas_flags = plan->math | rcas_opts | plan->out_policy | (p->hdr ? FSR1_FLAG_HDR_SQUARE : 0u);  // :125 Sample.x = hdr
+  if (p->fused != 0 && p->fused != 1 && p->fused != 2) return fail(FSR1_ERR_INVALID_ARGUMENT, "%s: params.fused must be 0, 1 or 2 (auto)", who);
+  const bool fused = p->fused == 1 || (p->fused == 2 && auto_takes_fused(in, have_intermediary, out, plan->easu_con, plan->math, have_stages));
+  if (!fused && !have_intermediary) return fail(FSR1_ERR_INVALID_ARGUMENT, "%s: two-pass EASU+RCAS needs an intermediary image", who);
+  plan->pipeline = fused ? 1 : 0;
+  return FSR1_OK;
+}
+
 int fsr1_upscale_ex(const fsr1_image* in, const fsr1_image* intermediary, const fsr1_image* out, const fsr1_params* p,
                     const fsr1_color_stages* stages, void* stream) {
   const Range range("upscale", in, out);
-  if (!in || !out || !p) return fail(FSR1_ERR_INVALID_ARGUMENT, "upscale: null argument");
-  if (!(p->render_width >= 1.0f) || !(p->render_height >= 1.0f) || p->render_width > (float)in->width || p->render_height > (float)in->height)
-    return fail(FSR1_ERR_INVALID_ARGUMENT, "upscale: render size %gx%g must lie within the input image %dx%d", (double)p->render_width,
-                (double)p->render_height, in->width, in->height);
-  uint32_t easu_con[16], rcas_con[4];
-  // :106 — viewport == input resource size == (renderWidth, renderHeight); output = display size
-  FsrEasuCon(easu_con, easu_con + 4, easu_con + 8, easu_con + 12, p->render_width, p->render_height, p->render_width,
-             p->render_height, (float)out->width, (float)out->height);
-  const uint32_t math = p->flags & (FSR1_FLAG_MATH_EXACT | FSR1_FLAG_MATH_PACKED_FP16 | FSR1_FLAG_NO_FAST_PATHS);
-  const uint32_t rcas_opts = p->flags & (FSR1_FLAG_RCAS_DENOISE | FSR1_FLAG_RCAS_PASSTHROUGH_ALPHA);
-  const uint32_t out_policy = p->flags & (FSR1_FLAG_OUTPUT_STREAMING | FSR1_FLAG_OUTPUT_CACHED);  // of the pass that writes `out`
-  if (p->flags & ~(math | rcas_opts | out_policy)) return fail(FSR1_ERR_INVALID_ARGUMENT, "upscale: params.flags may only hold MATH_*, RCAS_* and OUTPUT_* bits");
   if (stages && !stages->stages) stages = nullptr;
-  if (!p->use_rcas) {
+  UpscalePlan plan;
+  if (int rc = upscale_decide("upscale", in, intermediary != nullptr, out, p, stages != nullptr, &plan)) return rc;
+  if (plan.pipeline == 2) {
     // :107 Sample.x = hdr && !bUseRcas ; :140 EASU straight into the output
-    return fsr1_easu_dispatch_ex(in, out, easu_con, math | (p->hdr ? FSR1_FLAG_HDR_SQUARE : 0u) | (out_policy ? out_policy : (uint32_t)FSR1_FLAG_OUTPUT_STREAMING),
+    return fsr1_easu_dispatch_ex(in, out, plan.easu_con,
+                                 plan.math | (p->hdr ? FSR1_FLAG_HDR_SQUARE : 0u) | (plan.out_policy ? plan.out_policy : (uint32_t)FSR1_FLAG_OUTPUT_STREAMING),
                                  stages, stream);
   }
-  FsrRcasCon(rcas_con, p->rcas_attenuation);  // :124
-  const uint32_t rcas_flags = math | rcas_opts | out_policy | (p->hdr ? FSR1_FLAG_HDR_SQUARE : 0u);  // :125 Sample.x = hdr
-  if (p->fused != 0 && p->fused != 1 && p->fused != 2) return fail(FSR1_ERR_INVALID_ARGUMENT, "upscale: params.fused must be 0, 1 or 2 (auto)");
-  const bool fused = p->fused == 1 || (p->fused == 2 && auto_takes_fused(in, intermediary != nullptr, out, easu_con, math, stages != nullptr));
-  if (fused) return fsr1_easu_rcas_fused_dispatch_ex(in, out, easu_con, rcas_con, rcas_flags, stages, stream);
-  if (!intermediary) return fail(FSR1_ERR_INVALID_ARGUMENT, "upscale: two-pass EASU+RCAS needs an intermediary image");
+  if (plan.pipeline == 1) return fsr1_easu_rcas_fused_dispatch_ex(in, out, plan.easu_con, plan.rcas_con, plan.rcas_flags, stages, stream);
   // two dispatches: the prologue belongs to EASU's loads, the epilogue to RCAS's stores
   fsr1_color_stages pre, post;
   const fsr1_color_stages* pre_p = nullptr;
@@ -580,28 +637,22 @@ int fsr1_upscale_ex(const fsr1_image* in, const fsr1_image* intermediary, const 
     if (pre.stages) pre_p = &pre;
     if (post.stages) post_p = &post;
   }
-  int rc = fsr1_easu_dispatch_ex(in, intermediary, easu_con, math, pre_p, stream);  // :121 (Sample.x = 0 when RCAS follows)
+  int rc = fsr1_easu_dispatch_ex(in, intermediary, plan.easu_con, plan.math, pre_p, stream);  // :121 (Sample.x = 0 when RCAS follows)
   if (rc) return rc;
   // :130 the UAV->SRV barrier is stream order here
-  return fsr1_rcas_dispatch_ex(intermediary, out, rcas_con, rcas_flags, post_p, stream);  // :131
+  return fsr1_rcas_dispatch_ex(intermediary, out, plan.rcas_con, plan.rcas_flags, post_p, stream);  // :131
 }
 
 // Which pipeline fsr1_upscale[_ex] runs for these arguments (no launch): 0 = EASU + RCAS as two dispatches, 1 = the single
-// fused launch, 2 = EASU only (use_rcas == 0).
+// fused launch, 2 = EASU only (use_rcas == 0); the same validation as the call itself (upscale_decide).
 int fsr1_upscale_plan(const fsr1_image* in, int32_t have_intermediary, const fsr1_image* out, const fsr1_params* p, int32_t have_stages) {
-  if (!in || !out || !p) return fail(FSR1_ERR_INVALID_ARGUMENT, "upscale_plan: null argument");
-  if (!(p->render_width >= 1.0f) || !(p->render_height >= 1.0f) || out->width <= 0 || out->height <= 0 || out->frames <= 0)
-    return fail(FSR1_ERR_INVALID_ARGUMENT, "upscale_plan: bad extents");
-  if (!p->use_rcas) return 2;
-  if (p->fused == 0) return 0;
-  if (p->fused == 1) return 1;
-  if (p->fused != 2) return fail(FSR1_ERR_INVALID_ARGUMENT, "upscale_plan: params.fused must be 0, 1 or 2 (auto)");
-  uint32_t easu_con[16];
-  FsrEasuCon(easu_con, easu_con + 4, easu_con + 8, easu_con + 12, p->render_width, p->render_height, p->render_width, p->render_height,
-             (float)out->width, (float)out->height);
-  const uint32_t math = p->flags & (FSR1_FLAG_MATH_EXACT | FSR1_FLAG_MATH_PACKED_FP16 | FSR1_FLAG_NO_FAST_PATHS);
-  return auto_takes_fused(in, have_intermediary != 0, out, easu_con, math, have_stages != 0) ? 1 : 0;
+  UpscalePlan plan;
+  if (int rc = upscale_decide("upscale_plan", in, have_intermediary != 0, out, p, have_stages != 0, &plan)) return rc;
+  return plan.pipeline;
 }
+
+// Test hook: force the number of 16-row steps the exact-2x fused launch's workgroups walk (0 = the host's rule).
+void fsr1_debug_fused_run_steps(int32_t steps) { fused_s2_force_steps(steps); }
 
 int fsr1_selftest(uint32_t* failures) {
   if (!failures) return fail(FSR1_ERR_INVALID_ARGUMENT, "selftest: null");

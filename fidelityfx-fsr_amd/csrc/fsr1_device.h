@@ -16,15 +16,9 @@ namespace fsr1 {
 // Output tile of one 256-thread workgroup (4 waves): 64 x 16 pixels, each wave owns 4 rows, a
 // lane owns one column -> every global store instruction writes 64 consecutive pixels.
 constexpr int kTileW = 64;
-#ifndef FSR1_EASU_TILE_H
-#define FSR1_EASU_TILE_H 16
-#endif
-constexpr int kTileH = FSR1_EASU_TILE_H;  // multiple of 4 (rows are split over the four waves)
+constexpr int kTileH = 16;  // multiple of 4 (rows are split over the four waves); 8 / 12 / 24 / 32 measured slower at every ratio (profiles/ab_r02/c11_*)
 constexpr int kThreads = 256;
-#ifndef FSR1_FUSED_TILE_H
-#define FSR1_FUSED_TILE_H 16
-#endif
-constexpr int kFusedTileH = FSR1_FUSED_TILE_H;  // output rows per fused-kernel tile (multiple of 4)
+constexpr int kFusedTileH = 16;  // output rows per fused-kernel tile (multiple of 4)
 constexpr int kXcds = 8;  // MI355X: 8 XCDs, workgroup b is dispatched to XCD b % 8
 
 struct ColorPassArgs {

@@ -38,14 +38,10 @@ size_t easu_lds_bytes(int fmt, int fp_w, int fp_h) {
 
 // Compile-time LDS pitches of the generic kernel's row-interleaved layout (default arithmetic, plain pass).  A tile's footprint
 // is 64 * (in / out) + 4 texels wide: 46 at 1.5x, 42 at 1.7x, 54 at 1.3x.  0: the dense run-time layout (any width).
-#ifndef FSR1_EASU_NO_PITCHED
 int easu_lds_pitch(int fp_w, bool exact, bool color) {
   if (exact || color) return 0;
   return fp_w <= 48 ? 48 : (fp_w <= 56 ? 56 : (fp_w <= 64 ? 64 : 0));
 }
-#else
-int easu_lds_pitch(int, bool, bool) { return 0; }
-#endif
 
 // s2: launch the exact-2x variant (the caller has checked con0 and laid the grid out for the shifted tiles).
 hipError_t easu_launch(const EasuArgs& a, int fmt, bool exact, bool s2, hipStream_t stream) {

@@ -35,14 +35,16 @@ size_t fused_s2_lds_bytes(int fmt) {
 // single 4K frame (9 610 one-step tiles, five residencies of 256 CUs x 7 workgroups) loses with any S > 1 (2: +3 %, 3: +8 %,
 // 5: +18 %), four 4K frames or one 8K frame (38 440) gain 4.5 % at S = 4 (2: 1-2 %, 6: 2 %, 8: -1 %), sixteen 8K frames
 // (613 000) gain 6.3 % at S = 8 (6: 5.7 %, 10: 5.9 %, 16: 4.5 %) — so: about five residencies of runs, at most 8 steps.
-#ifndef FSR1_FUSED_S2_MAX_STEPS
-#define FSR1_FUSED_S2_MAX_STEPS 8
-#endif
-int fused_s2_run_steps(int width, int height, int frames) {
-  if (const char* e = getenv("FSR1_FUSED_S2_STEPS"); e && atoi(e) > 0) return atoi(e);  // tuning runs and tests/test_gpu_parity.py: any S gives the same image
+constexpr int kFs2MaxSteps = 8;
+// Test hook (fsr1_debug_fused_run_steps, include/fsr1_hip.h): a forced number of steps per run, 0 = the rule below.  Any number gives
+// the same image (tests/test_gpu_parity.py::test_fused_exact_2x_run_steps); tuning runs set it through the same call.
+static std::atomic<int> g_fs2_forced_steps{0};
+void fused_s2_force_steps(int steps) { g_fs2_forced_steps.store(steps < 0 ? 0 : (steps > 64 ? 64 : steps), std::memory_order_relaxed); }
+int fused_s2_run_steps(int width, int height, int frames, int cus) {
+  if (const int forced = g_fs2_forced_steps.load(std::memory_order_relaxed); forced > 0) return forced;
   const long long tiles1 = (long long)((width + kFs2OutW - 1) / kFs2OutW) * ((height + kFs2Step - 3) / (kFs2Step - 2)) * frames;
-  const long long s = tiles1 / (5 * 256 * 7);
-  return (int)(s < 1 ? 1 : s > FSR1_FUSED_S2_MAX_STEPS ? FSR1_FUSED_S2_MAX_STEPS : s);
+  const long long s = tiles1 / (5ll * (cus > 0 ? cus : 256) * 7);  // (cus: the device's compute units — 256 on MI355X, where the rule was measured)
+  return (int)(s < 1 ? 1 : s > kFs2MaxSteps ? kFs2MaxSteps : s);
 }
 
 void fused_s2_geometry(int width, int height, int steps, int* tiles_x, int* tiles_y) {

@@ -20,10 +20,9 @@
 //   * texels outside the image are 0 (the D3D `Load` rule of the reference's callback, FSR_Pass.hlsl:45,61).
 #include "fsr1_rcas_kernel.h"
 
-#ifndef FSR1_RCAS_SHALLOW_RING
-#define FSR1_RCAS_SHALLOW_RING 2
-#endif
 namespace fsr1 {
+
+constexpr int kRcasShallowRing = 2;  // rows in flight per lane when the launch is short of waves (a single 4K frame)
 
 // Strip height.  Measured on MI355X at 3840x2160 (gpurun_out/): the pass runs at the same ~34 us for
 // 8..16-row strips and slows down beyond (24 rows 39 us, 32 rows 42-46 us, 64 rows 67 us) even when the
@@ -33,12 +32,8 @@ namespace fsr1 {
 // waves per SIMD, then 8.
 void rcas_geometry(int width, int height, int frames, int* tiles_x, int* tiles_y, int* rows) {
   const int tx = (width + kRcasCols - 1) / kRcasCols;
-#ifdef FSR1_RCAS_ROWS
-  int r = FSR1_RCAS_ROWS;
-#else
   int r = 16;
   if ((long long)tx * ((height + r - 1) / r) * frames * kRcasWaves < 4LL * 4 * 256) r = 8;
-#endif
   *rows = r;
   *tiles_x = tx;
   *tiles_y = (height + r - 1) / r;
@@ -48,14 +43,10 @@ hipError_t rcas_launch(const RcasArgs& a, int fmt, bool exact, hipStream_t strea
   const dim3 grid((unsigned)(a.tiles_x * a.tiles_y * a.frames)), block(kRcasThreads);
   const bool opts = (a.flags & (FSR1_FLAG_RCAS_DENOISE | FSR1_FLAG_RCAS_PASSTHROUGH_ALPHA | FSR1_FLAG_HDR_SQUARE)) != 0;
   // shallow ring when the image is short of waves: fewer than 6 per SIMD in 16-row strips (RGBA32F: always 4 rows)
-#ifdef FSR1_RCAS_FORCE_SHALLOW  // tuning experiment
-  const bool shallow = true; (void)kRcasRing;
-#else
   const bool shallow = (long long)a.tiles_x * ((a.in.height + 15) / 16) * a.frames * kRcasWaves < 6LL * 4 * 256;
-#endif
 #define FSR1_RCAS(F, E, O)                                                                                                                  \
   do {                                                                                                                                      \
-    if (shallow) hipLaunchKernelGGL((rcas_kernel<F, E, O, false, F, (F == FSR1_FORMAT_RGBA32F ? 4 : FSR1_RCAS_SHALLOW_RING)>), grid, block, 0, stream, a);       \
+    if (shallow) hipLaunchKernelGGL((rcas_kernel<F, E, O, false, F, (F == FSR1_FORMAT_RGBA32F ? 4 : kRcasShallowRing)>), grid, block, 0, stream, a);       \
     else hipLaunchKernelGGL((rcas_kernel<F, E, O, false, F, (F == FSR1_FORMAT_RGBA32F ? 4 : kRcasRing)>), grid, block, 0, stream, a);       \
   } while (0)
 #define FSR1_RCAS_O(F, E) do { if (opts) FSR1_RCAS(F, E, true); else FSR1_RCAS(F, E, false); } while (0)

@@ -15,14 +15,8 @@
 
 namespace fsr1 {
 
-#ifndef FSR1_RCASH_ROWS
-#define FSR1_RCASH_ROWS 8
-#endif
-#ifndef FSR1_RCASH_WAVES
-#define FSR1_RCASH_WAVES 2
-#endif
-constexpr int kRcasHRows = FSR1_RCASH_ROWS;   // rows per strip, a multiple of the 4-row ring.  Measured at 4K, us (profiles/ab_r02/r2c9_ab.log): 8 rows 26.7, 16 rows 27.1, 32 rows 31.7; round 1's 24 rows x 4 waves, fully unrolled: 31.0
-constexpr int kRcasHWaves = FSR1_RCASH_WAVES; // waves per workgroup, side by side: the F kernel's shape (fsr1_rcas_kernel.h)
+constexpr int kRcasHRows = 8;   // rows per strip, a multiple of the 4-row ring.  Measured at 4K, us (profiles/ab_r02/r2c9_ab.log): 8 rows 26.7, 16 rows 27.1, 32 rows 31.7; round 1's 24 rows x 4 waves, fully unrolled: 31.0
+constexpr int kRcasHWaves = 2; // waves per workgroup, side by side: the F kernel's shape (fsr1_rcas_kernel.h)
 constexpr int kRcasHThreads = 64 * kRcasHWaves;
 constexpr int kRcasHCols = 128 * kRcasHWaves;  // columns per workgroup
 constexpr int kShr1 = 0x138, kShl1 = 0x130;

@@ -7,17 +7,11 @@
 
 namespace fsr1 {
 
-#ifndef FSR1_RCAS_WAVES
-#define FSR1_RCAS_WAVES 2
-#endif
-#ifndef FSR1_RCAS_RING
-#define FSR1_RCAS_RING 8
-#endif
 constexpr int kRcasWaveCols = 128;        // columns per wave (two per lane)
-constexpr int kRcasWaves = FSR1_RCAS_WAVES;          // waves per workgroup, side by side
+constexpr int kRcasWaves = 2;             // waves per workgroup, side by side
 constexpr int kRcasThreads = 64 * kRcasWaves;
 constexpr int kRcasCols = kRcasWaveCols * kRcasWaves;  // columns per workgroup
-constexpr int kRcasRing = FSR1_RCAS_RING;            // rows in flight per lane (RGBA16F); strips are a multiple of it tall
+constexpr int kRcasRing = 8;              // rows in flight per lane (RGBA16F, batches); strips are a multiple of it tall
 // fp32 texel of the lane to the left / right; `keep` stays where the neighbour lane does not exist
 template <int CTRL>
 __device__ __forceinline__ rgb_t neighbour(rgb_t keep, rgb_t v) {
@@ -34,13 +28,10 @@ template <> struct RcasPair<FSR1_FORMAT_R10G10B10A2_UNORM> { typedef uint32_t T 
 // image, so nothing is predicated except the apron load of lanes 0 / 63.
 // COLOR: colour stages fused in (fsr1_device_color.hpp) — FsrSrtmF on every tap as it is loaded (the role of the
 // FsrRcasInputF callback, ffx_fsr1.h:682), FsrLfgaF / FsrSrtmInvF / FsrTepdC*F on the result before it is stored as FOUT.
-// UP: the strip is walked from its last row to its first (interior strips only).  Vertically adjacent strips walk in
-// opposite directions, so the two apron rows they share are read by both at the same end of their lives — close in
-// time, the second reader from L2 — instead of ~a kernel duration apart.
 // XEDGE (with INTERIOR): the strip's own 128 columns and every row it reads are inside the image, but it is the image's first
 // and / or last wave-column: the apron column of lane 0 and / or lane 63 is outside, i.e. 0 (FSR_Pass.hlsl:45,61).  The interior
 // body with that one texel replaced, instead of the fully predicated one (2 of 30 wave-columns at 3840 pixels).
-template <int FMT, bool EXACT, bool OPTS, bool INTERIOR, bool COLOR, int FOUT, int RING, bool UP = false, bool XEDGE = false>
+template <int FMT, bool EXACT, bool OPTS, bool INTERIOR, bool COLOR, int FOUT, int RING, bool XEDGE = false>
 __device__ __forceinline__ void rcas_strip(const RcasArgs& a, int frame, int x0, int y0, int lane) {
   typedef typename Pixel<FMT>::T texel_t;
   typedef typename RcasPair<FMT>::T pair_t;
@@ -67,23 +58,15 @@ __device__ __forceinline__ void rcas_strip(const RcasArgs& a, int frame, int x0,
   auto zext = [](uint32_t o) { asm("" : "+v"(o)); return (size_t)o; };
 
   const int rows = a.rows;
-  auto row_y = [&](int k) { return UP ? y0 + rows - 1 - k : y0 + k; };  // k-th row of the walk, k = -1 .. rows
+  auto row_y = [&](int k) { return y0 + k; };  // k-th row of the walk, k = -1 .. rows
   struct row_t { texel_t p0, p1, halo; };
   auto load = [&](int y, row_t& r) {
     if (!INTERIOR) r.halo = Pixel<FMT>::zero();
     if (INTERIOR) {
-#ifdef FSR1_RCAS_NT_LOAD  // tuning experiment
-      const pair_t pr = __builtin_nontemporal_load(reinterpret_cast<const pair_t*>(in_frame + (long long)y * a.in.pitch + zext(off)));
-#else
       const pair_t pr = *reinterpret_cast<const pair_t*>(in_frame + (long long)y * a.in.pitch + zext(off));
-#endif
       __builtin_memcpy(&r.p0, &pr, sizeof(texel_t));
       __builtin_memcpy(&r.p1, reinterpret_cast<const char*>(&pr) + sizeof(texel_t), sizeof(texel_t));
-#ifdef FSR1_RCAS_NO_HALO  // timing experiment only (wrong at strip edges)
-      r.halo = r.p0;
-#else
       r.halo = *reinterpret_cast<const texel_t*>(in_frame + (long long)y * a.in.pitch + zext(hoff));
-#endif
       if constexpr (XEDGE) {
         if (halo_out) r.halo = Pixel<FMT>::zero();
       }
@@ -137,14 +120,9 @@ __device__ __forceinline__ void rcas_strip(const RcasArgs& a, int frame, int x0,
       // horizontal neighbours: pixel 0's left = the left lane's pixel 1, pixel 1's right = the right lane's pixel 0;
       // lanes 0 / 63 keep their apron texel
       const rgb_t d0 = neighbour<kDppWaveShr1>(hal, cur1), f1 = neighbour<kDppWaveShl1>(hal, cur0);
-#ifdef FSR1_RCAS_COPY_ONLY  // tuning experiment: memory pattern without the arithmetic
-      rgb_t o0 = {prev0.r + d0.r, cur0.g + next0.g, cur1.b}, o1 = {prev1.r + f1.r, cur1.g + next1.g, cur0.b};
-      (void)sharp;
-#else
-      // b is the tap above, h the one below (ffx_fsr1.h:697-707): when walking up, `prev` is the row below
-      rgb_t o0 = UP ? rcas_pixel<EXACT>(next0, d0, cur0, cur1, prev0, sharp, flags) : rcas_pixel<EXACT>(prev0, d0, cur0, cur1, next0, sharp, flags);
-      rgb_t o1 = UP ? rcas_pixel<EXACT>(next1, cur0, cur1, f1, prev1, sharp, flags) : rcas_pixel<EXACT>(prev1, cur0, cur1, f1, next1, sharp, flags);
-#endif
+      // b is the tap above, h the one below (ffx_fsr1.h:697-707)
+      rgb_t o0 = rcas_pixel<EXACT>(prev0, d0, cur0, cur1, next0, sharp, flags);
+      rgb_t o1 = rcas_pixel<EXACT>(prev1, cur0, cur1, f1, next1, sharp, flags);
       if (INTERIOR || y < H) {
         const bool alpha = (flags & FSR1_FLAG_RCAS_PASSTHROUGH_ALPHA) != 0;  // :700-705 / FSR_Pass.hlsl:94
         if constexpr (COLOR) {
@@ -186,12 +164,8 @@ __global__ void __launch_bounds__(kRcasThreads) rcas_kernel(const RcasArgs a) {
   const bool interior_y = y0 >= 1 - a.rows_above && y0 + a.rows + 1 <= a.in.height + a.rows_below &&
                           y0 + a.rows <= a.in.height;  // (the interior body stores every row of the strip)
   const bool interior = interior_y && x0 >= 1 && x0 + kRcasWaveCols + 1 <= a.in.width;
-#ifdef FSR1_RCAS_ALTERNATE
-  if (interior && (ty & 1)) rcas_strip<FMT, EXACT, OPTS, true, COLOR, FOUT, RING, true>(a, frame, x0, y0, lane);
-  else
-#endif
   if (interior) rcas_strip<FMT, EXACT, OPTS, true, COLOR, FOUT, RING>(a, frame, x0, y0, lane);
-  else if (interior_y && x0 + kRcasWaveCols <= a.in.width) rcas_strip<FMT, EXACT, OPTS, true, COLOR, FOUT, RING, false, true>(a, frame, x0, y0, lane);
+  else if (interior_y && x0 + kRcasWaveCols <= a.in.width) rcas_strip<FMT, EXACT, OPTS, true, COLOR, FOUT, RING, true>(a, frame, x0, y0, lane);
   else rcas_strip<FMT, EXACT, OPTS, false, COLOR, FOUT, RING>(a, frame, x0, y0, lane);
 }
 

@@ -283,6 +283,11 @@ int fsr1_device_count(void);
  * that the reference's ARcpH1/ARcpH2/ARcpF1 (ffx_a.h:1005, GLSL `1.0/x`) are pinned to. */
 int fsr1_selftest(uint32_t* failures);
 
+/* Test hook (process-wide, not part of the reference's surface): force the number of 16-row steps the workgroups of the exact-2x
+ * fused launch walk down their columns (fsr1_fused_s2.hip), clamped to 0 .. 64; 0 restores the host's rule.  Every value gives
+ * the same image, bit for bit — which is what tests/test_gpu_parity.py::test_fused_exact_2x_run_steps uses it to show. */
+void fsr1_debug_fused_run_steps(int32_t steps);
+
 /* HIP-event stopwatch on a caller stream (used by the bench so that kernel time is measured on the
  * very stream the kernels run on).  Handles are opaque. */
 int fsr1_timer_create(void** timer);

@@ -596,10 +596,10 @@ def test_fused_exact_2x_quad_form(fsr, shape):
 
 @pytest.mark.parametrize("steps", [1, 2, 3, 4, 5, 9, 11])
 @pytest.mark.parametrize("shape", [(97, 160), (31, 75), (64, 40), (70, 9)], ids=lambda s: "%dx%d" % s)
-def test_fused_exact_2x_run_steps(fsr, monkeypatch, shape, steps):
+def test_fused_exact_2x_run_steps(fsr, shape, steps):
     """The exact-2x fused kernel walks down its 62-pixel column in `steps` steps of 16 EASU rows, carrying the last two rows of a
     step to the next in an 18-row LDS ring (fsr1_fused_s2.hip).  The host picks `steps` from the launch's size; whatever it is —
-    forced here through FSR1_FUSED_S2_STEPS, 9 steps take the ring through every one of its positions — the image is the same,
+    forced here through the fsr1_debug_fused_run_steps test hook, 9 steps take the ring through every one of its positions — the image is the same,
     bit for bit, as the two dispatches', for whole images, batches and row bands."""
     iw, ih = shape
     ow, oh = 2 * iw, 2 * ih
@@ -610,17 +610,19 @@ def test_fused_exact_2x_run_steps(fsr, monkeypatch, shape, steps):
         two = torch.zeros_like(mid)
         fsr.easu(src, mid, flags=flags & fsr.FLAG_MATH_EXACT)
         fsr.rcas(mid, two, sharpness=0.3, flags=flags)
-        monkeypatch.setenv("FSR1_FUSED_S2_STEPS", str(steps))
-        big_out = torch.full((n, oh + 1, ow + 5, 4), 7, dtype=torch.float16, device="cuda")
-        dst = big_out[:, :oh, :ow]
-        fsr.easu_rcas_fused(src, dst, sharpness=0.3, flags=flags)
-        torch.cuda.synchronize()
-        assert bool((big_out[:, oh:] == 7).all()) and bool((big_out[:, :, ow:] == 7).all()), "wrote outside the output view"
-        assert torch.equal(dst.view(torch.int16), two.view(torch.int16)), "steps %d != two dispatches (flags %d)" % (steps, flags)
-        band = torch.full_like(two[0], -1.0)
-        cuts = [0, (oh // 3) & ~1, (2 * oh // 3) & ~1, oh]
-        for y0, y1 in zip(cuts, cuts[1:]):
-            if y1 > y0:
-                fsr.upscale_band(src[0], band[y0:y1], (ow, oh), (y0, y1), sharpness=0.3, flags=flags, fused=True)
-        assert torch.equal(band.view(torch.int16), two[0].view(torch.int16)), "bands at steps %d != two dispatches (flags %d)" % (steps, flags)
-        monkeypatch.delenv("FSR1_FUSED_S2_STEPS")
+        fsr.load().fsr1_debug_fused_run_steps(steps)
+        try:
+            big_out = torch.full((n, oh + 1, ow + 5, 4), 7, dtype=torch.float16, device="cuda")
+            dst = big_out[:, :oh, :ow]
+            fsr.easu_rcas_fused(src, dst, sharpness=0.3, flags=flags)
+            torch.cuda.synchronize()
+            assert bool((big_out[:, oh:] == 7).all()) and bool((big_out[:, :, ow:] == 7).all()), "wrote outside the output view"
+            assert torch.equal(dst.view(torch.int16), two.view(torch.int16)), "steps %d != two dispatches (flags %d)" % (steps, flags)
+            band = torch.full_like(two[0], -1.0)
+            cuts = [0, (oh // 3) & ~1, (2 * oh // 3) & ~1, oh]
+            for y0, y1 in zip(cuts, cuts[1:]):
+                if y1 > y0:
+                    fsr.upscale_band(src[0], band[y0:y1], (ow, oh), (y0, y1), sharpness=0.3, flags=flags, fused=True)
+            assert torch.equal(band.view(torch.int16), two[0].view(torch.int16)), "bands at steps %d != two dispatches (flags %d)" % (steps, flags)
+        finally:
+            fsr.load().fsr1_debug_fused_run_steps(0)

@@ -16,9 +16,10 @@ LIB = os.path.join(ROOT, "fidelityfx-fsr_amd", "libfsr1_hip.so")
 
 
 @pytest.fixture(scope="module")
-def meta():
-    if not os.path.exists(LIB):
-        pytest.skip("libfsr1_hip.so not built")
+def meta(fsr):
+    # (the `fsr` fixture builds the library when it is missing: this check never skips — the waves_per_eu budgets on the EASU and
+    #  fused templates turn a kernel that outgrows them into silent spills, and this is the guard)
+    assert os.path.exists(LIB)
     import kernel_meta
     m = kernel_meta.kernel_meta(LIB)
     assert len(m) > 100, "expected every kernel instantiation of the library"
@@ -57,3 +58,22 @@ def test_walking_fused_kernel_fits_seven_workgroups_of_sgprs(meta):
     for k, v in meta.items():
         if k.startswith("fsr1::fused_s2_kernel<"):
             assert 800 // ((v["sgpr"] + 15) // 16 * 16 + 16) >= 7, (k, v)
+
+
+def test_no_experiment_switches_in_the_product_sources():
+    """Tuning experiments live as patches under tools/experiments_r0x/, not as `#ifdef FSR1_...` blocks in the kernels (a mistyped -D
+    would build a wrong-answer library), and the library reads no tuning value from the environment on a launch path."""
+    import glob
+    import re
+    hits = []
+    for f in glob.glob(os.path.join(ROOT, "fidelityfx-fsr_amd", "csrc", "*")) + glob.glob(os.path.join(ROOT, "include", "*")):
+        if not f.endswith((".hip", ".h", ".hpp", ".c")):
+            continue
+        for n, line in enumerate(open(f), 1):
+            if re.match(r"\s*#\s*ifdef\s+FSR1_", line) or re.match(r"\s*#\s*if\s+defined\s*\(?\s*FSR1_", line):
+                hits.append("%s:%d: %s" % (os.path.relpath(f, ROOT), n, line.strip()))
+            if re.match(r"\s*#\s*ifndef\s+FSR1_", line) and not re.search(r"_(H|HPP)\b", line):
+                hits.append("%s:%d: %s" % (os.path.relpath(f, ROOT), n, line.strip()))
+            if "getenv(" in line and "FSR1_ROCTX" not in line:
+                hits.append("%s:%d: %s" % (os.path.relpath(f, ROOT), n, line.strip()))
+    assert not hits, hits
