@@ -21,6 +21,9 @@
 //     fsr1::FsrRcasF<EXACT>(r, g, b, a, ip, con, MyRcas{...});                              //   FSR_RCAS_PASSTHROUGH_ALPHA
 //     fsr1::FsrEasuH(pixh, ip, con0, con1, con2, con3, MyEasuH{...});                       // ffx_fsr1.h:505-512
 //     fsr1::FsrRcasH(rh, gh, bh, ip, con, MyRcasH{...});                                    // ffx_fsr1.h:782-790
+//     fsr1::FsrRcasHx2(r2, g2, b2, ip, con, MyRcasHx2{...});                                // ffx_fsr1.h:889-984: pixels ip and ip + (8, 0)
+//     fsr1::FsrRcasDepackHx2(pix0, pix1, r2, g2, b2);                                       // ffx_fsr1.h:880-887
+//     fsr1::ARmp8x8(lane)                                                                   // ffx_a.h:2304: the 64 -> 8x8 remap of mainCS
 //
 // con0..con3 / con are the words FsrEasuCon / FsrRcasCon (include/fsr1_hip.h, bit-exact with the reference) produce.
 // EXACT = true follows the reference's operation order and is bit-identical to the reference's FsrEasuF / FsrRcasF
@@ -163,35 +166,92 @@ __device__ __forceinline__ void FsrEasuH(half3_t& pix, uint2 ip, uint4 con0, uin
 
 // ---------------------------------------------------------------------------------------------------------------------
 // FsrRcasH — ffx_fsr1.h:782-866.  Callbacks: half4 FsrRcasLoadH(short2 p), void FsrRcasInputH(half&, half&, half&) (:779-780).
-// Evaluated through the two-pixel form (FsrRcasHx2's arithmetic is FsrRcasH's, lane by lane) with both lanes equal.
+// One pixel, scalar binary16 operations (rcas_pixel_h1): equal, bit for bit, to the matching lane of the two-pixel form.
 // ---------------------------------------------------------------------------------------------------------------------
 namespace detail {
 template <bool DENOISE, class Callbacks>
-__device__ __forceinline__ rgbh2_t rcas_h(half_t* pixA, uint2 ip, uint4 con, const Callbacks& cb) {
+__device__ __forceinline__ rgbh1_t rcas_h(half_t* pixA, uint2 ip, uint4 con, const Callbacks& cb) {
   const short2 sp = {(short)ip.x, (short)ip.y};  // :795 ASW2(ip)
-  struct tap_t { half2_t r, g, b; };
+  struct tap_t { half_t r, g, b; };
   auto tap = [&](int dx, int dy, half_t* alpha) {
     const half4_t t = cb.FsrRcasLoadH(short2{(short)(sp.x + dx), (short)(sp.y + dy)});
     half_t r = t.x, g = t.y, b = t.z;
     if (alpha) *alpha = t.w;
     cb.FsrRcasInputH(r, g, b);
-    return tap_t{h2s(r), h2s(g), h2s(b)};
+    return tap_t{r, g, b};
   };
   const tap_t b = tap(0, -1, nullptr), d = tap(-1, 0, nullptr), e = tap(0, 0, pixA), f = tap(1, 0, nullptr), h = tap(0, 1, nullptr);
   const half_t sharp1 = __builtin_bit_cast(half_t, (u16)(con.y & 0xffffu));  // :857 AH2_AU1(con.y).x
-  return rcas_pixel_h2(b.r, b.g, b.b, d.r, d.g, d.b, e.r, e.g, e.b, f.r, f.g, f.b, h.r, h.g, h.b, sharp1, DENOISE ? (uint32_t)FSR1_FLAG_RCAS_DENOISE : 0u);
+  return rcas_pixel_h1(b.r, b.g, b.b, d.r, d.g, d.b, e.r, e.g, e.b, f.r, f.g, f.b, h.r, h.g, h.b, sharp1, DENOISE ? (uint32_t)FSR1_FLAG_RCAS_DENOISE : 0u);
 }
 }  // namespace detail
 
 template <bool DENOISE = false, class Callbacks>
 __device__ __forceinline__ void FsrRcasH(half_t& pixR, half_t& pixG, half_t& pixB, uint2 ip, uint4 con, const Callbacks& cb) {
-  const rgbh2_t p = detail::rcas_h<DENOISE>(nullptr, ip, con, cb);
-  pixR = p.r.x; pixG = p.g.x; pixB = p.b.x;
+  const rgbh1_t p = detail::rcas_h<DENOISE>(nullptr, ip, con, cb);
+  pixR = p.r; pixG = p.g; pixB = p.b;
 }
 template <bool DENOISE = false, class Callbacks>
 __device__ __forceinline__ void FsrRcasH(half_t& pixR, half_t& pixG, half_t& pixB, half_t& pixA, uint2 ip, uint4 con, const Callbacks& cb) {
-  const rgbh2_t p = detail::rcas_h<DENOISE>(&pixA, ip, con, cb);
-  pixR = p.r.x; pixG = p.g.x; pixB = p.b.x;
+  const rgbh1_t p = detail::rcas_h<DENOISE>(&pixA, ip, con, cb);
+  pixR = p.r; pixG = p.g; pixB = p.b;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// FsrRcasHx2 — ffx_fsr1.h:889-984 (FSR_RCAS_HX2): TWO pixels per call, `ip` and `ip + (8, 0)` — the left and the right 8x8 tile
+// of a 16x8 region — in the .x / .y halves of every operand.  Callbacks (:876-877):
+//   half4 FsrRcasLoadHx2(short2 p);  void FsrRcasInputHx2(half2& r, half2& g, half2& b);
+// FsrRcasDepackHx2 (:880-887) turns the packed result back into two pixels for the store.
+// ---------------------------------------------------------------------------------------------------------------------
+namespace detail {
+template <bool DENOISE, class Callbacks>
+__device__ __forceinline__ rgbh2_t rcas_hx2(half2_t* pixA, uint2 ip, uint4 con, const Callbacks& cb) {
+  const short2 sp0 = {(short)ip.x, (short)ip.y};            // :903 ASW2(ip)
+  const short2 sp1 = {(short)(sp0.x + 8), sp0.y};           // :915
+  struct tap_t { half2_t r, g, b; };
+  auto tap = [&](int dx, int dy, half2_t* alpha) {           // :904-939 loads + AoS -> SoA
+    const half4_t t0 = cb.FsrRcasLoadHx2(short2{(short)(sp0.x + dx), (short)(sp0.y + dy)});
+    const half4_t t1 = cb.FsrRcasLoadHx2(short2{(short)(sp1.x + dx), (short)(sp1.y + dy)});
+    if (alpha) *alpha = h2(t0.w, t1.w);
+    return tap_t{h2(t0.x, t1.x), h2(t0.y, t1.y), h2(t0.z, t1.z)};
+  };
+  tap_t b = tap(0, -1, nullptr), d = tap(-1, 0, nullptr), e = tap(0, 0, pixA), f = tap(1, 0, nullptr), h = tap(0, 1, nullptr);
+  cb.FsrRcasInputHx2(b.r, b.g, b.b);                         // :941-945, in the reference's order
+  cb.FsrRcasInputHx2(d.r, d.g, d.b);
+  cb.FsrRcasInputHx2(e.r, e.g, e.b);
+  cb.FsrRcasInputHx2(f.r, f.g, f.b);
+  cb.FsrRcasInputHx2(h.r, h.g, h.b);
+  const half_t sharp1 = __builtin_bit_cast(half_t, (u16)(con.y & 0xffffu));  // :975 AH2_AU1(con.y).x
+  return rcas_pixel_h2(b.r, b.g, b.b, d.r, d.g, d.b, e.r, e.g, e.b, f.r, f.g, f.b, h.r, h.g, h.b, sharp1, DENOISE ? (uint32_t)FSR1_FLAG_RCAS_DENOISE : 0u);
+}
+}  // namespace detail
+
+template <bool DENOISE = false, class Callbacks>
+__device__ __forceinline__ void FsrRcasHx2(half2_t& pixR, half2_t& pixG, half2_t& pixB, uint2 ip, uint4 con, const Callbacks& cb) {
+  const rgbh2_t p = detail::rcas_hx2<DENOISE>(nullptr, ip, con, cb);
+  pixR = p.r; pixG = p.g; pixB = p.b;
+}
+// FSR_RCAS_PASSTHROUGH_ALPHA (:897-899, :907-909, :919-921): pixA = the two centre taps' alpha
+template <bool DENOISE = false, class Callbacks>
+__device__ __forceinline__ void FsrRcasHx2(half2_t& pixR, half2_t& pixG, half2_t& pixB, half2_t& pixA, uint2 ip, uint4 con, const Callbacks& cb) {
+  const rgbh2_t p = detail::rcas_hx2<DENOISE>(&pixA, ip, con, cb);
+  pixR = p.r; pixG = p.g; pixB = p.b;
+}
+// :880-887 — packed structure-of-arrays back to two pixels; alpha = 0 like the reference's A_HLSL branch (its GLSL branch leaves
+// it unwritten): the caller writes 1 or the passed-through alpha.
+__device__ __forceinline__ void FsrRcasDepackHx2(half4_t& pix0, half4_t& pix1, half2_t pixR, half2_t pixG, half2_t pixB) {
+  pix0 = half4_t{pixR.x, pixG.x, pixB.x, (half_t)0.0f};
+  pix1 = half4_t{pixR.y, pixG.y, pixB.y, (half_t)0.0f};
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// ARmp8x8 — ffx_a.h:2304: "simple remap 64x1 to 8x8 with rotated 2x2 pixel quads in quad linear" — lane bits 543210 -> x = bits 3..1,
+// y = bits 5,4 and 0.  The dispatch contract of the reference's shader shell (FSR_Pass.hlsl:110-117: a 64-lane workgroup covers
+// 16 x 16 pixels as four 8x8 tiles, gxy = ARmp8x8(lane) + 16 * workgroup).  The library's own kernels use tile shapes of their own.
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __host__ __forceinline__ uint2 ARmp8x8(uint32_t a) {
+  return uint2{(a >> 1) & 7u,                       // ABfe(a, 1, 3)
+               (((a >> 3) & 7u) & ~1u) | (a & 1u)};  // ABfiM(ABfe(a, 3, 3), a, 1): bit 0 of a inserted under bits 5..4
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -234,6 +294,8 @@ struct ImageCallbacks {
     return half4_t{(half_t)t.x, (half_t)t.y, (half_t)t.z, (half_t)t.w};
   }
   __device__ __forceinline__ void FsrRcasInputH(half_t&, half_t&, half_t&) const {}
+  __device__ __forceinline__ half4_t FsrRcasLoadHx2(short2 p) const { return FsrRcasLoadH(p); }
+  __device__ __forceinline__ void FsrRcasInputHx2(half2_t&, half2_t&, half2_t&) const {}
 };
 
 }  // namespace fsr1

@@ -298,4 +298,46 @@ __device__ __forceinline__ rgbh2_t rcas_pixel_h2(half2_t bR, half2_t bG, half2_t
   return rgbh2_t{pR, pG, pB};
 }
 
+// FsrRcasH for ONE pixel (:782-866): the same operation list as rcas_pixel_h2 on scalar binary16 operands (v_*_f16 instead of
+// v_pk_*_f16 — each operation rounds to binary16 either way, so the value equals the corresponding lane of the two-pixel form,
+// and an outside kernel that sharpens one pixel per lane does not pay for two).
+__device__ __forceinline__ half_t prx_med_rcp1(half_t a) {  // APrxMedRcpH1, ffx_a.h:1815
+  const half_t b = __builtin_bit_cast(half_t, (u16)(0x778du - __builtin_bit_cast(u16, a)));
+  return b * (-b * a + (half_t)2.0f);
+}
+struct rgbh1_t { half_t r, g, b; };
+__device__ __forceinline__ rgbh1_t rcas_pixel_h1(half_t bR, half_t bG, half_t bB, half_t dR, half_t dG, half_t dB, half_t eR, half_t eG, half_t eB,
+                                                 half_t fR, half_t fG, half_t fB, half_t hR, half_t hG, half_t hB, half_t sharp, uint32_t flags) {
+  const half_t hlf = (half_t)0.5f, qtr = (half_t)0.25f, four = (half_t)4.0f, one = (half_t)1.0f, zero = (half_t)0.0f, m4 = (half_t)-4.0f;
+  auto mn3h = [](half_t x, half_t y, half_t z) { return hmin1(x, hmin1(y, z)); };  // AMin3H1, ffx_a.h:1149
+  auto mx3h = [](half_t x, half_t y, half_t z) { return hmax1(x, hmax1(y, z)); };
+  // :828-833 min and max of ring
+  const half_t mn4R = hmin1(mn3h(bR, dR, fR), hR), mn4G = hmin1(mn3h(bG, dG, fG), hG), mn4B = hmin1(mn3h(bB, dB, fB), hB);
+  const half_t mx4R = hmax1(mx3h(bR, dR, fR), hR), mx4G = hmax1(mx3h(bG, dG, fG), hG), mx4B = hmax1(mx3h(bB, dB, fB), hB);
+  // :835-843 limiters (peakC = (1, -4))
+  const half_t hitMinR = hmin1(mn4R, eR) * hrcp1(four * mx4R);
+  const half_t hitMinG = hmin1(mn4G, eG) * hrcp1(four * mx4G);
+  const half_t hitMinB = hmin1(mn4B, eB) * hrcp1(four * mx4B);
+  const half_t hitMaxR = (one - hmax1(mx4R, eR)) * hrcp1(four * mn4R + m4);
+  const half_t hitMaxG = (one - hmax1(mx4G, eG)) * hrcp1(four * mn4G + m4);
+  const half_t hitMaxB = (one - hmax1(mx4B, eB)) * hrcp1(four * mn4B + m4);
+  const half_t lobeR = hmax1(-hitMinR, hitMaxR), lobeG = hmax1(-hitMinG, hitMaxG), lobeB = hmax1(-hitMinB, hitMaxB);
+  half_t lobe = hmax1((half_t)(-(0.25f - (1.0f / 16.0f))), hmin1(mx3h(lobeR, lobeG, lobeB), zero)) * sharp;  // :847
+  if (flags & FSR1_FLAG_RCAS_DENOISE) {  // :817-826, :849-851
+    const half_t bL = bB * hlf + (bR * hlf + bG), dL = dB * hlf + (dR * hlf + dG), eL = eB * hlf + (eR * hlf + eG);
+    const half_t fL = fB * hlf + (fR * hlf + fG), hL = hB * hlf + (hR * hlf + hG);
+    half_t nz = qtr * bL + qtr * dL + qtr * fL + qtr * hL - eL;
+    nz = hmin1(hmax1(habs1(nz) * prx_med_rcp1(mx3h(mx3h(bL, dL, eL), fL, hL) - mn3h(mn3h(bL, dL, eL), fL, hL)), zero), one);
+    nz = (half_t)-0.5f * nz + one;
+    lobe = lobe * nz;
+  }
+  // :853-856 resolve
+  const half_t rcpL = prx_med_rcp1(four * lobe + one);
+  half_t pR = (lobe * bR + lobe * dR + lobe * hR + lobe * fR + eR) * rcpL;
+  half_t pG = (lobe * bG + lobe * dG + lobe * hG + lobe * fG + eG) * rcpL;
+  half_t pB = (lobe * bB + lobe * dB + lobe * hB + lobe * fB + eB) * rcpL;
+  if (flags & FSR1_FLAG_HDR_SQUARE) { pR = pR * pR; pG = pG * pG; pB = pB * pB; }  // FSR_Pass.hlsl:92-93
+  return rgbh1_t{pR, pG, pB};
+}
+
 }  // namespace fsr1

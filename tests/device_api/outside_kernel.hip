@@ -1,8 +1,9 @@
 // An integrator's own HIP translation unit, written against include/ ONLY (no file of the library's csrc/ is visible
 // to this compile: see the Makefile's -I list).  It plays the role of the reference's includer, sample/src/DX12/FSR_Pass.hlsl:
 // defines the load callbacks, calls the per-pixel entry points FsrEasuF / FsrRcasF / FsrEasuH / FsrRcasH from kernels of
-// its own shape (one thread per output pixel, 16x16 blocks), and — second half — uses the LDS-staged fast form the
-// library itself runs.  tests/test_device_api.py checks every result bit-for-bit against the golden vectors generated
+// its own shape (one thread per output pixel, 16x16 blocks), runs the reference's own shader shell (64 lanes, ARmp8x8, four
+// pixels per lane; FsrRcasHx2 + FsrRcasDepackHx2 as the packed form of the same shell), and — last — uses the LDS-staged fast
+// form the library itself runs.  tests/test_device_api.py checks every result bit-for-bit against the golden vectors generated
 // from the reference headers.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -58,6 +59,57 @@ __global__ void rcas_h_kernel(ImageCallbacks<FSR1_FORMAT_RGBA16F> cb, half4_t* o
   if (ALPHA) FsrRcasH<DENOISE>(r, g, b, a, ip, con, cb);
   else FsrRcasH<DENOISE>(r, g, b, ip, con, cb);
   out[(size_t)ip.y * w + ip.x] = half4_t{r, g, b, a};
+}
+
+// ---- the reference's shader shell, FSR_Pass.hlsl:106-118, written the way an integrator who copies it would: a 64-lane workgroup,
+//      gxy = ARmp8x8(lane) + 16 * workgroup, CurrFilter on the four 8x8 tiles of a 16x16 region.  PASS 0: SAMPLE_EASU (FsrEasuH),
+//      PASS 1: SAMPLE_RCAS (FsrRcasH), PASS 2: the packed two-pixel entry point the header offers for the same shell — FsrRcasHx2
+//      covers gxy and gxy + (8, 0) in one call (ffx_fsr1.h:889-893), so a lane makes two calls instead of four — plus
+//      FsrRcasDepackHx2 for the store.  A texture store outside the resource is dropped by the API; here it is a bounds check. ----
+template <int PASS, bool DENOISE>
+__global__ void __launch_bounds__(64) shader_shell_kernel(ImageCallbacks<FSR1_FORMAT_RGBA16F> cb, half4_t* out, int ow, int oh, Con k, int hdr) {
+  auto store = [&](uint2 pos, half_t r, half_t g, half_t b) {
+    if (hdr) { r = r * r; g = g * g; b = b * b; }                                      // `if (Sample.x == 1) c *= c;`
+    if ((int)pos.x < ow && (int)pos.y < oh) out[(size_t)pos.y * ow + pos.x] = half4_t{r, g, b, (half_t)1.0f};  // OutputTexture[pos] = AH4(c, 1)
+  };
+  auto CurrFilter = [&](uint2 pos) {
+    if (PASS == 0) {
+      half3_t c;
+      FsrEasuH(c, pos, k.c0, k.c1, k.c2, k.c3, cb);
+      store(pos, c.x, c.y, c.z);
+    } else {
+      half_t r, g, b;
+      FsrRcasH<DENOISE>(r, g, b, pos, k.c0, cb);
+      store(pos, r, g, b);
+    }
+  };
+  const uint2 rm = ARmp8x8(threadIdx.x);
+  uint2 gxy = {rm.x + (blockIdx.x << 4u), rm.y + (blockIdx.y << 4u)};
+  if (PASS == 2) {
+    for (int half_tile = 0; half_tile < 2; ++half_tile) {
+      half2_t r2, g2, b2;
+      FsrRcasHx2<DENOISE>(r2, g2, b2, gxy, k.c0, cb);
+      half4_t p0, p1;
+      FsrRcasDepackHx2(p0, p1, r2, g2, b2);
+      store(gxy, p0.x, p0.y, p0.z);
+      store(uint2{gxy.x + 8u, gxy.y}, p1.x, p1.y, p1.z);
+      gxy.y += 8u;
+    }
+    return;
+  }
+  CurrFilter(gxy);
+  gxy.x += 8u;
+  CurrFilter(gxy);
+  gxy.y += 8u;
+  CurrFilter(gxy);
+  gxy.x -= 8u;
+  CurrFilter(gxy);
+}
+
+__global__ void rmp8x8_kernel(uint32_t* xy) {
+  const uint2 r = ARmp8x8(threadIdx.x);
+  xy[2 * threadIdx.x] = r.x;
+  xy[2 * threadIdx.x + 1] = r.y;
 }
 
 // ---- the LDS-staged fast form: a 32 x 32 output tile per 256-thread block (a shape of this file's own choosing) ----
@@ -138,6 +190,30 @@ int outside_rcas_h(const void* in, int w, int h, void* out, const uint32_t* con4
 #define RUN(D, A) hipLaunchKernelGGL((rcas_h_kernel<D, A>), grid2(w, h), dim3(16, 16), 0, nullptr, cb, o, w, h, con)
   switch (variant & 3) { case 0: RUN(false, false); break; case 1: RUN(true, false); break; case 2: RUN(false, true); break; default: RUN(true, true); break; }
 #undef RUN
+  return done();
+}
+
+// pass: 0 = EASU (con16 = FsrEasuCon's words), 1 = RCAS through FsrRcasH, 2 = RCAS through FsrRcasHx2 (con16[0..3] = FsrRcasCon's words);
+// `in` is iw x ih, `out` ow x oh (RCAS: the same size); denoise = FSR_RCAS_DENOISE; hdr = Sample.x
+int outside_shader_shell(const void* in, int iw, int ih, void* out, int ow, int oh, const uint32_t* con16, int pass, int denoise, int hdr) {
+  const ImageCallbacks<FSR1_FORMAT_RGBA16F> cb = {static_cast<const char*>(in), iw, ih, (long long)iw * 8};
+  const dim3 grid((ow + 15) / 16, (oh + 15) / 16);
+  half4_t* o = static_cast<half4_t*>(out);
+  Con k = make_con(con16);
+#define RUN(P, D) hipLaunchKernelGGL((shader_shell_kernel<P, D>), grid, dim3(64), 0, nullptr, cb, o, ow, oh, k, hdr)
+  switch (pass * 2 + (denoise ? 1 : 0)) {
+    case 0: case 1: RUN(0, false); break;
+    case 2: RUN(1, false); break; case 3: RUN(1, true); break;
+    case 4: RUN(2, false); break; case 5: RUN(2, true); break;
+    default: return -1;
+  }
+#undef RUN
+  return done();
+}
+
+// ARmp8x8 of lanes 0 .. 63 -> xy[128] (device pointer)
+int outside_rmp8x8(void* xy) {
+  hipLaunchKernelGGL(rmp8x8_kernel, dim3(1), dim3(64), 0, nullptr, static_cast<uint32_t*>(xy));
   return done();
 }
 

@@ -158,6 +158,23 @@ def test_upscale_plan_auto_rule(fsr):
     assert plan(1920, 1080, 960, 540, flags=1 << 5) == 0
     assert plan(1920, 1080, 3840, 2160, fused=3) == -1 and b"fused" in lib.fsr1_last_error()
     assert lib.fsr1_upscale_plan(None, 1, None, None, 0) == -1
+    # the plan refuses what the call refuses (one validation, upscale_decide): render size outside the input, illegal flag
+    # combinations and unknown bits, packed fp16 on a non-RGBA16F image or with colour stages, two dispatches without an intermediary
+    def plan_raw(a, b, prm, have_mid=1, stages=0):
+        return lib.fsr1_upscale_plan(ctypes.byref(a), have_mid, ctypes.byref(b), ctypes.byref(prm), stages)
+    img = lambda w, h, fmt=0, frames=1: fsr.fsr1_image(0x1000, w, h, fmt, frames, 0, 0)  # noqa: E731
+    assert plan_raw(img(1920, 1080), img(3840, 2160), P(2000.0, 1080.0, 1, 0.25, 0, 2, 0)) == -1 and b"render size" in lib.fsr1_last_error()
+    assert plan_raw(img(1920, 1080), img(3840, 2160), P(1920.0, 1080.0, 1, 0.25, 0, 2, (1 << 4) | (1 << 5))) == -1 and b"exclusive" in lib.fsr1_last_error()
+    assert plan_raw(img(1920, 1080), img(3840, 2160), P(1920.0, 1080.0, 1, 0.25, 0, 2, 1 << 20)) == -1 and b"unknown flag" in lib.fsr1_last_error()
+    assert plan_raw(img(1920, 1080), img(3840, 2160), P(1920.0, 1080.0, 1, 0.25, 0, 2, 1 << 0)) == -1 and b"params.flags" in lib.fsr1_last_error()
+    assert plan_raw(img(1920, 1080, 1), img(3840, 2160, 1), P(1920.0, 1080.0, 1, 0.25, 0, 2, 1 << 5)) == -2 and b"RGBA16F" in lib.fsr1_last_error()
+    assert plan_raw(img(1920, 1080), img(3840, 2160), P(1920.0, 1080.0, 1, 0.25, 0, 2, 1 << 5), stages=1) == -2
+    assert plan_raw(img(1920, 1080), img(3840, 2160), P(1920.0, 1080.0, 1, 0.25, 0, 0, 0), have_mid=0) == -1 and b"intermediary" in lib.fsr1_last_error()
+    assert plan_raw(img(1920, 1080, 0, 2), img(3840, 2160, 0, 3), P(1920.0, 1080.0, 1, 0.25, 0, 2, 0)) == -1 and b"frame counts" in lib.fsr1_last_error()
+    assert plan_raw(img(1920, 1080, 7), img(3840, 2160), P(1920.0, 1080.0, 1, 0.25, 0, 2, 0)) == -2 and b"format" in lib.fsr1_last_error()
+    assert plan_raw(img(1920, 1080), img(0, 2160), P(1920.0, 1080.0, 1, 0.25, 0, 2, 0)) == -1
+    # a partial viewport (dynamic resolution: render size smaller than the resource) is what the call accepts, so the plan does too
+    assert plan_raw(img(1920, 1080), img(3840, 2160), P(1280.0, 720.0, 1, 0.25, 0, 2, 0)) == 0
 
 
 @pytest.mark.gpu

@@ -20,7 +20,7 @@ from conftest import PIXEL_CASES, ROOT, load_golden
 
 HERE = os.path.join(ROOT, "tests", "device_api")
 LIB = os.path.join(HERE, "liboutside_kernel.so")
-ENTRY_POINTS = ["outside_easu_f", "outside_rcas_f", "outside_easu_h", "outside_rcas_h", "outside_easu_tiled"]
+ENTRY_POINTS = ["outside_easu_f", "outside_rcas_f", "outside_easu_h", "outside_rcas_h", "outside_easu_tiled", "outside_shader_shell", "outside_rmp8x8"]
 
 
 def build_outside():
@@ -75,6 +75,8 @@ def outside():
     lib.outside_easu_h.argtypes = [vp, ip, ip, vp, ip, ip, up]
     lib.outside_rcas_h.argtypes = [vp, ip, ip, vp, up, ip]
     lib.outside_easu_tiled.argtypes = [vp, ip, ip, vp, ip, ip, up, ip]
+    lib.outside_shader_shell.argtypes = [vp, ip, ip, vp, ip, ip, up, ip, ip, ip]
+    lib.outside_rmp8x8.argtypes = [vp]
     return lib
 
 
@@ -180,3 +182,78 @@ def test_outside_h_entry_points_match_goldens(outside, name):
         o2 = torch.zeros_like(mid)
         assert outside.outside_rcas_h(mid.data_ptr(), ow, oh, o2.data_ptr(), rconp, variant) == 0
         _same16(o2.cpu().numpy(), g["rcas_h_%d" % variant], "%s FsrRcasH variant %d" % (name, variant))
+
+
+def _armp8x8(a):
+    """ffx_a.h:2304: AU2(ABfe(a,1,3), ABfiM(ABfe(a,3,3), a, 1))"""
+    return ((a >> 1) & 7, (((a >> 3) & 7) & ~1) | (a & 1))
+
+
+def test_public_header_exports_the_reference_operator_list():
+    """The source-level surface names every operator of the reference's list for this path (Missing 2)."""
+    hdr = open(os.path.join(ROOT, "include", "fsr1_device.hpp")).read()
+    for name in ("void FsrEasuF(", "void FsrRcasF(", "void FsrEasuH(", "void FsrRcasH(", "void FsrRcasHx2(", "void FsrRcasDepackHx2(", "uint2 ARmp8x8("):
+        assert name in hdr, name
+    assert "rcas_pixel_h1" in hdr  # FsrRcasH is a one-pixel evaluation, not the two-pixel form with both lanes equal
+
+
+@gpu
+def test_armp8x8_from_an_outside_kernel(outside, ref):
+    """fsr1::ARmp8x8 (ffx_a.h:2304) on the device against the reference's own function compiled into oracle/_ref, all 64 lanes: a
+    permutation of the 8x8 tile in rotated 2x2 quads."""
+    import torch
+    xy = torch.zeros(128, dtype=torch.int32, device="cuda")
+    assert outside.outside_rmp8x8(xy.data_ptr()) == 0
+    got = xy.cpu().numpy().reshape(64, 2)
+    b = (ctypes.c_uint32 * 2)()
+    for lane in range(64):
+        ref.lib.ref_rmp8x8(ctypes.c_uint32(lane), b)
+        assert tuple(got[lane]) == (b[0], b[1]) == _armp8x8(lane), lane
+    assert len({tuple(r) for r in got}) == 64
+
+
+@gpu
+@pytest.mark.parametrize("name", PIXEL_CASES)
+def test_shader_shell_from_an_outside_kernel(outside, name):
+    """A kernel written exactly like the reference's mainCS (FSR_Pass.hlsl:106-118: 64 lanes, ARmp8x8, four pixels per lane) over the
+    public header: EASU through FsrEasuH, RCAS through FsrRcasH, and RCAS through the packed FsrRcasHx2 + FsrRcasDepackHx2 (two
+    calls per lane) — every image bit-identical to the goldens of the reference's H path, ragged sizes included."""
+    import torch
+    g = load_golden(name)
+    ih, iw = g["input"].shape[:2]
+    oh, ow = g["easu_h"].shape[:2]
+    src = _dev(g["input"].astype(np.float16))
+    out = torch.full((oh, ow, 4), -3.0, dtype=torch.float16, device="cuda")
+    con, conp = _u32(g["con"])
+    assert outside.outside_shader_shell(src.data_ptr(), iw, ih, out.data_ptr(), ow, oh, conp, 0, 0, 0) == 0
+    _same16(out.cpu().numpy(), g["easu_h"], name + " mainCS-shaped FsrEasuH")
+    mid = _dev(g["mid"].astype(np.float16))
+    rcon = np.zeros(16, np.uint32)
+    rcon[:4] = g["rcas_con"]
+    rcon, rconp = _u32(rcon)
+    for denoise in (0, 1):  # goldens rcas_h_0 / rcas_h_1
+        for pass_ in (1, 2):
+            o2 = torch.full((oh, ow, 4), -3.0, dtype=torch.float16, device="cuda")
+            assert outside.outside_shader_shell(mid.data_ptr(), ow, oh, o2.data_ptr(), ow, oh, rconp, pass_, denoise, 0) == 0
+            _same16(o2.cpu().numpy(), g["rcas_h_%d" % denoise], "%s mainCS-shaped %s denoise %d" % (name, "FsrRcasH" if pass_ == 1 else "FsrRcasHx2", denoise))
+
+
+@gpu
+def test_hx2_from_an_outside_kernel_against_the_reference_hx2(outside, ref):
+    """... and against the reference's own FsrRcasHx2 (compiled into oracle/_ref) on a width that is not a multiple of 16, with the HDR
+    square of the shell applied after it."""
+    import torch
+    import importlib
+    frames = importlib.import_module("fidelityfx-fsr_amd.frames")
+    if not ref.has_hx2:
+        pytest.skip("this oracle/_ref build has no FsrRcasHx2")
+    w, h = 203, 37
+    img = frames.synthetic_frame(w, h, k=11, dtype=np.float16)
+    con = np.zeros(16, np.uint32)
+    con[:4] = ref.FsrRcasCon(0.4)
+    con, conp = _u32(con)
+    want = ref.rcas_hx2(img.astype(np.float32), con[:4], 0)
+    for pass_ in (1, 2):
+        out = torch.zeros(h, w, 4, dtype=torch.float16, device="cuda")
+        assert outside.outside_shader_shell(_dev(img).data_ptr(), w, h, out.data_ptr(), w, h, conp, pass_, 0, 0) == 0
+        _same16(out.cpu().numpy()[..., :3], want[..., :3], "pass %d vs the reference's FsrRcasHx2" % pass_)

@@ -126,6 +126,30 @@ def test_easu_band_window_with_x_origin(fsr):
         assert torch.equal(win, full[y0:y0 + h, x0:x0 + w]), (x0, y0, w, h)
 
 
+def test_upscale_band_with_a_caller_supplied_intermediary(fsr):
+    """upscale_band takes a scratch intermediary of at least band rows + 3 (one EASU row either side, one more for the even start);
+    a buffer sized to the old "+ 2" contract is refused, never silently truncated (that was an out-of-bounds read)."""
+    iw, ih, ow, oh = 64, 40, 128, 80
+    src = dev(frames.synthetic_frame(iw, ih, k=5, dtype=np.float16))
+    mid_full = torch.zeros(oh, ow, 4, dtype=torch.float16, device="cuda")
+    full = torch.zeros_like(mid_full)
+    fsr.easu(src, mid_full)
+    fsr.rcas(mid_full, full, sharpness=0.25)
+    out = torch.full_like(full, -1.0)
+    for (y0, y1) in ((0, 26), (26, 54), (54, 80)):  # even cuts: the middle band's intermediary starts two rows above it
+        scratch = torch.full((y1 - y0 + 3 + 2, ow, 4), 9.0, dtype=torch.float16, device="cuda")  # two guard rows behind
+        fsr.upscale_band(src, out[y0:y1], (ow, oh), (y0, y1), mid=scratch, sharpness=0.25)
+        torch.cuda.synchronize()
+        assert bool((scratch[-2:] == 9.0).all()), "wrote beyond the rows the band needs"
+    assert torch.equal(out.view(torch.int16), full.view(torch.int16))
+    with pytest.raises(fsr.Fsr1Error, match="intermediary"):  # rows + 2: too small for an even interior cut
+        fsr.upscale_band(src, out[26:54], (ow, oh), (26, 54), mid=torch.zeros(28 + 2, ow, 4, dtype=torch.float16, device="cuda"))
+    with pytest.raises(fsr.Fsr1Error, match="intermediary"):  # wrong width
+        fsr.upscale_band(src, out[26:54], (ow, oh), (26, 54), mid=torch.zeros(40, ow + 2, 4, dtype=torch.float16, device="cuda"))
+    with pytest.raises(fsr.Fsr1Error, match="dtype"):
+        fsr.upscale_band(src, out[26:54], (ow, oh), (26, 54), mid=torch.zeros(40, ow, 4, dtype=torch.float32, device="cuda"))
+
+
 def test_band_argument_validation(fsr):
     src = dev(frames.synthetic_frame(32, 18, k=1, dtype=np.float16))
     band = torch.zeros(10, 64, 4, dtype=torch.float16, device="cuda")
