@@ -598,6 +598,11 @@ static int upscale_decide(const char* who, const fsr1_image* in, bool have_inter
   memcpy(&by, &plan->easu_con[3], 4);
   const int fp_w = footprint_extent(out->width, kTileW, 0, sx, bx), fp_h = footprint_extent(out->height, kTileH, 0, sy, by);
   if (fp_w < 0 || fp_h < 0) return fail(FSR1_ERR_INVALID_ARGUMENT, "%s: scale constants con0.xy = (%g, %g) are not usable", who, sx, sy);
+  const bool packed = (plan->math & FSR1_FLAG_MATH_PACKED_FP16) != 0;
+  if (!p->use_rcas || p->fused != 1) {  // an EASU dispatch will run (alone, or as the first of two, or as what `auto` may pick)
+    if (easu_lds_bytes(in->format, fp_w, fp_h) > 160 * 1024)
+      return fail(FSR1_ERR_UNSUPPORTED, "%s: input/output ratio (%g, %g) needs a %dx%d texel footprint per tile, beyond the LDS budget", who, sx, sy, fp_w, fp_h);
+  }
   if (!p->use_rcas) {
     plan->pipeline = 2;
     return FSR1_OK;
@@ -607,6 +612,11 @@ static int upscale_decide(const char* who, const fsr1_image* in, bool have_inter
   if (p->fused != 0 && p->fused != 1 && p->fused != 2) return fail(FSR1_ERR_INVALID_ARGUMENT, "%s: params.fused must be 0, 1 or 2 (auto)", who);
   const bool fused = p->fused == 1 || (p->fused == 2 && auto_takes_fused(in, have_intermediary, out, plan->easu_con, plan->math, have_stages));
   if (!fused && !have_intermediary) return fail(FSR1_ERR_INVALID_ARGUMENT, "%s: two-pass EASU+RCAS needs an intermediary image", who);
+  if (fused) {  // the fused launch's own LDS bound (fused_dispatch_impl)
+    const int ffw = footprint_extent(out->width, kTileW, 1, sx, bx), ffh = footprint_extent(out->height, kFusedTileH, 1, sy, by);
+    if (ffw < 0 || ffh < 0 || (packed ? fused_h_lds_bytes(ffw, ffh) : fused_lds_bytes(in->format, ffw, ffh)) > 160 * 1024)
+      return fail(FSR1_ERR_UNSUPPORTED, "%s: input/output ratio (%g, %g) needs more LDS than a CU has for the fused launch", who, sx, sy);
+  }
   plan->pipeline = fused ? 1 : 0;
   return FSR1_OK;
 }

@@ -15,12 +15,18 @@
  *
  *   fsr1_runner [--gpus N] [--frames F] [--in WxH] [--out WxH] [--steps K] [--warmup W]
  *               [--pipeline two-pass|fused|easu|auto] [--math f|exact|h] [--sharpness STOPS] [--hdr]
- *               [--stages BITS] [--grain AMOUNT] [--ring R] [--bands]
+ *               [--stages BITS] [--grain AMOUNT] [--ring R] [--bands] [--dry-run [--dry-fail RANK]]
  *
  * --bands: strong scaling of ONE frame stream instead of weak scaling over frames — every GPU holds the whole
  * input frame and produces one band of output rows (fsr1_easu_dispatch_band on the band plus a row either side, then
  * fsr1_rcas_dispatch_band, or with --pipeline fused the single launch fsr1_easu_rcas_fused_dispatch_band); still no image
  * byte crosses a link.
+ *
+ * --dry-run: the host side of an N-GPU run with no device behind it — N threads, the contiguous frame shards, the pipeline plan
+ * (fsr1_upscale_plan is host arithmetic), K "steps" of 1 ms of sleep, the barrier every rank reaches before the collective, the
+ * abort path (--dry-fail RANK makes that rank fail before the barrier: the others must not hang, the exit code is 1), the gather of
+ * the counters (by the host instead of RCCL) and the one JSON line, marked "dry_run": true.  What a CPU-only builder can check of
+ * `--gpus 8` (tests/test_runner.py).
  *
  * --stages fuses colour stages into the passes (FSR1_COLOR_* bits of fsr1_hip.h: 1 FsrSrtmF on the input, 2 FsrLfgaF
  * film grain, 4 FsrSrtmInvF, 8 / 16 FsrTepdC8F / FsrTepdC10F dither) — what the sample's colour pass does around the
@@ -36,6 +42,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include "fsr1_hip.h"
 
@@ -48,6 +55,8 @@ typedef struct {
   float grain;
   int ring; /* input / output sets to rotate over; 0 = enough to exceed 1 GiB (four times the Infinity Cache) */
   int bands; /* 1: one frame per step, split into row bands over the GPUs */
+  int dry;   /* 1: --dry-run (no device, no RCCL) */
+  int dry_fail; /* --dry-fail RANK: that rank reports a failure before the barrier (-1: none) */
 } options_t;
 
 /* A rank that fails must not leave the others blocked in the collective: every rank reaches this barrier, failed or
@@ -307,6 +316,36 @@ static int worker_body(worker_t* w) {
   return 0;
 }
 
+/* --dry-run: a rank's work without a device: its shard, the plan, K steps of 1 ms, its counters */
+static int worker_body_dry(worker_t* w) {
+  const options_t* o = w->opt;
+  int f0, f1;
+  shard(o->frames, w->rank, o->gpus, &f0, &f1);
+  const int nf = f1 - f0;
+  fsr1_params p;
+  memset(&p, 0, sizeof p);
+  p.render_width = (float)o->in_w;
+  p.render_height = (float)o->in_h;
+  p.use_rcas = o->pipeline != 2;
+  p.rcas_attenuation = o->sharpness;
+  p.hdr = o->hdr;
+  p.fused = o->pipeline == 1 ? 1 : (o->pipeline == 3 ? 2 : 0);
+  p.flags = o->math;
+  fsr1_image pin = {NULL, o->in_w, o->in_h, FSR1_FORMAT_RGBA16F, nf > 0 ? nf : 1, 0, 0}, pout = {NULL, o->out_w, o->out_h, FSR1_FORMAT_RGBA16F, nf > 0 ? nf : 1, 0, 0};
+  w->plan = fsr1_upscale_plan(&pin, o->pipeline == 0 || o->pipeline == 3, &pout, &p, o->stages != 0);
+  if (w->plan < 0) { snprintf(w->error, sizeof w->error, "fsr1_upscale_plan: %s", fsr1_last_error()); w->status = w->plan; return -1; }
+  if (w->rank == o->dry_fail) { snprintf(w->error, sizeof w->error, "--dry-fail: rank %d fails before the collective", w->rank); w->status = -1; return -1; }
+  struct timespec t0, t1, ms1 = {0, 1000000};
+  clock_gettime(CLOCK_MONOTONIC, &t0);
+  for (int i = 0; i < o->steps; ++i) nanosleep(&ms1, NULL);
+  clock_gettime(CLOCK_MONOTONIC, &t1);
+  w->ring = 0;
+  w->counters[0] = (uint64_t)nf * (uint64_t)o->steps;
+  w->counters[1] = w->counters[0] * (uint64_t)o->out_w * (uint64_t)o->out_h;
+  w->counters[2] = (uint64_t)((t1.tv_sec - t0.tv_sec) * 1000000000ll + (t1.tv_nsec - t0.tv_nsec));
+  return 0;
+}
+
 /* the one collective: all-gather of 3 x uint64 per GPU over RCCL */
 static int worker_collective(worker_t* w) {
   const options_t* o = w->opt;
@@ -319,8 +358,12 @@ static int worker_collective(worker_t* w) {
 
 static void* worker(void* arg) {
   worker_t* w = (worker_t*)arg;
-  if (worker_body(w) != 0) atomic_store(&g_abort, 1);
+  if ((w->opt->dry ? worker_body_dry(w) : worker_body(w)) != 0) atomic_store(&g_abort, 1);
   pthread_barrier_wait(&g_before_collective);  /* every rank arrives, failed or not */
+  if (w->opt->dry) {  /* the gather of the counters, by the host: each rank's three words into rank 0's table */
+    if (!atomic_load(&g_abort)) memcpy(w->gathered + 3 * w->rank, w->counters, sizeof w->counters);
+    return NULL;
+  }
   if (!atomic_load(&g_abort)) (void)worker_collective(w);
   (void)hipFree(w->d_send); (void)hipFree(w->d_recv);
   (void)hipFree(w->d_in); (void)hipFree(w->d_mid); (void)hipFree(w->d_out); (void)hipFree(w->d_noise);
@@ -338,17 +381,20 @@ static void usage(void) {
        "                   [--stages BITS] [--grain AMOUNT]   (colour stages: 1 SRTM, 2 grain, 4 SRTM inverse, 8/16 TEPD 8/10-bit)\n"
        "                   [--ring R]   (input / output sets to rotate over; default: more than 1 GiB, 4 x the Infinity Cache)\n"
        "                   [--bands]    (one frame stream split into row bands over the GPUs instead of frames per GPU)\n"
+       "                   [--dry-run [--dry-fail RANK]]   (the N-thread host side without devices or RCCL: shards, plan, barrier, abort path, JSON)\n"
        "defaults: 1 GPU, 1 frame per GPU, 1920x1080 -> 3840x2160, 100 steps, 10 warmup, two-pass, f, 0.25 stops");
 }
 
 int main(int argc, char** argv) {
-  options_t o = {1, 0, 1920, 1080, 3840, 2160, 100, 10, 0, 0, 0u, 0.25f, 0u, 0.25f, 0, 0};
+  options_t o = {1, 0, 1920, 1080, 3840, 2160, 100, 10, 0, 0, 0u, 0.25f, 0u, 0.25f, 0, 0, 0, -1};
   for (int i = 1; i < argc; ++i) {
     const char* a = argv[i];
     const char* v = i + 1 < argc ? argv[i + 1] : NULL;
     if (!strcmp(a, "--help") || !strcmp(a, "-h")) { usage(); return 0; }
     else if (!strcmp(a, "--hdr")) o.hdr = 1;
     else if (!strcmp(a, "--bands")) o.bands = 1;
+    else if (!strcmp(a, "--dry-run")) o.dry = 1;
+    else if (!strcmp(a, "--dry-fail") && v) { o.dry_fail = atoi(v); ++i; }
     else if (!v) { fprintf(stderr, "missing value for %s\n", a); return 2; }
     else if (!strcmp(a, "--gpus")) { o.gpus = atoi(v); ++i; }
     else if (!strcmp(a, "--frames")) { o.frames = atoi(v); ++i; }
@@ -374,7 +420,8 @@ int main(int argc, char** argv) {
   }
   if (o.gpus < 1 || o.steps < 1 || o.warmup < 0) { usage(); return 2; }
   if (o.frames <= 0) o.frames = o.gpus; /* one frame per GPU */
-  const int visible = fsr1_device_count();
+  if (o.dry && o.bands) { fprintf(stderr, "--dry-run exercises the frames-per-GPU path\n"); return 2; }
+  const int visible = o.dry ? o.gpus : fsr1_device_count();  /* --dry-run: a pretended device count */
   if (visible < 0) { fprintf(stderr, "cannot enumerate GPUs: %s\n", fsr1_last_error()); return 1; }
   if (visible < o.gpus) { fprintf(stderr, "need %d GPUs, %d visible\n", o.gpus, visible); return 1; }
   if (o.bands && (o.pipeline > 1 || o.stages || (o.math & FSR1_FLAG_MATH_PACKED_FP16))) {
@@ -389,8 +436,10 @@ int main(int argc, char** argv) {
   ncclComm_t* comms = (ncclComm_t*)calloc((size_t)o.gpus, sizeof *comms);
   int* devs = (int*)calloc((size_t)o.gpus, sizeof *devs);
   for (int i = 0; i < o.gpus; ++i) devs[i] = i;
-  ncclResult_t nr = ncclCommInitAll(comms, o.gpus, devs);
-  if (nr != ncclSuccess) { fprintf(stderr, "ncclCommInitAll: %s\n", ncclGetErrorString(nr)); return 1; }
+  if (!o.dry) {
+    ncclResult_t nr = ncclCommInitAll(comms, o.gpus, devs);
+    if (nr != ncclSuccess) { fprintf(stderr, "ncclCommInitAll: %s\n", ncclGetErrorString(nr)); return 1; }
+  }
 
   worker_t* ws = (worker_t*)calloc((size_t)o.gpus, sizeof *ws);
   pthread_t* th = (pthread_t*)calloc((size_t)o.gpus, sizeof *th);
@@ -421,19 +470,20 @@ int main(int argc, char** argv) {
     printf("{\"metric\": \"upscaled megapixels/sec\", \"value\": %.1f, \"unit\": \"Mpix/s\", \"n_gpus\": %d, \"frames\": %llu, "
            "\"steps\": %d, \"warmup\": %d, \"ms_per_step\": %.5f, \"seconds\": %.6f, \"higher_is_better\": true, \"scaling\": \"%s\", "
            "\"in\": \"%dx%d\", \"out\": \"%dx%d\", \"pipeline\": \"%s\", \"pipeline_run\": \"%s\", \"math\": \"%s\", \"color_stages\": %u, "
-           "\"algorithmic_GBps\": %.1f, \"hbm_peak_frac\": %.4f, \"rccl_ranks\": %d, \"world_size_seen\": %d, \"ring\": %d, \"intermediary\": \"%s\", \"bands\": %d, \"per_gpu_ms\": [",
+           "\"algorithmic_GBps\": %.1f, \"hbm_peak_frac\": %.4f, \"rccl_ranks\": %d, \"world_size_seen\": %d, \"ring\": %d, \"intermediary\": \"%s\", \"bands\": %d, \"dry_run\": %s, \"per_gpu_ms\": [",
            (double)pixels / sec / 1e6, o.gpus, (unsigned long long)frames, o.steps, o.warmup, sec * 1e3 / o.steps, sec, o.bands ? "strong" : "weak",
            o.in_w, o.in_h, o.out_w, o.out_h,
            o.pipeline == 0 ? "two-pass" : (o.pipeline == 1 ? "fused" : (o.pipeline == 2 ? "easu" : "auto")),
            ran == 0 ? "two-pass" : (ran == 1 ? "fused" : "easu"), o.math == FSR1_FLAG_MATH_EXACT ? "exact" : (o.math ? "h" : "f"), o.stages, bytes / sec / 1e9,
-           bytes / sec / 1e9 / (8000.0 * o.gpus), o.gpus, ws[0].comm_ranks, ws[0].ring, ran == 0 ? "reused" : "none", o.bands);
+           bytes / sec / 1e9 / (8000.0 * o.gpus), o.dry ? 0 : o.gpus, o.dry ? o.gpus : ws[0].comm_ranks, ws[0].ring, ran == 0 ? "reused" : "none", o.bands,
+           o.dry ? "true" : "false");
     for (int i = 0; i < o.gpus; ++i) printf("%s%.3f", i ? ", " : "", (double)gathered[3 * i + 2] * 1e-6);
     printf("], \"per_rank_seconds\": [");
     for (int i = 0; i < o.gpus; ++i) printf("%s%.6f", i ? ", " : "", (double)gathered[3 * i + 2] * 1e-9);
     printf("]}\n");
   }
   pthread_barrier_destroy(&g_before_collective);
-  for (int i = 0; i < o.gpus; ++i) ncclCommDestroy(comms[i]);
+  if (!o.dry) for (int i = 0; i < o.gpus; ++i) ncclCommDestroy(comms[i]);
   free(comms); free(devs); free(ws); free(th); free(gathered);
   return rc;
 }

@@ -25,6 +25,36 @@ def test_runner_builds_and_parses_arguments(runner):
     assert subprocess.run([runner, "--bogus", "1"], capture_output=True).returncode == 2
 
 
+@pytest.mark.parametrize("gpus", [1, 2, 8])
+def test_runner_dry_run_host_side_of_n_gpus(runner, gpus):
+    """`runner --gpus N --dry-run`: the N-thread host side with no device behind it — contiguous frame shards, the plan, the barrier
+    every rank reaches before the collective, the gather of the counters, ONE JSON line with world_size_seen == N and N
+    per_rank_seconds (BASELINE configs[2]'s shape at N = 8: 64 frames, 8 per GPU, 1440p -> 4K, `auto` -> two dispatches)."""
+    out = subprocess.run([runner, "--dry-run", "--gpus", str(gpus), "--frames", str(8 * gpus), "--in", "2560x1440", "--out", "3840x2160", "--steps", "6",
+                          "--pipeline", "auto"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["dry_run"] is True and d["n_gpus"] == gpus and d["world_size_seen"] == gpus and d["rccl_ranks"] == 0
+    assert len(d["per_rank_seconds"]) == gpus == len(d["per_gpu_ms"]) and min(d["per_rank_seconds"]) >= 0.006
+    assert d["frames"] == 8 * gpus * 6 and d["scaling"] == "weak" and d["pipeline_run"] == "two-pass"
+    assert abs(d["seconds"] - max(d["per_rank_seconds"])) < 1e-6  # MAX over ranks
+    # uneven shards: 11 frames over 8 ranks are 2 2 2 1 1 1 1 1, all of them counted
+    out = subprocess.run([runner, "--dry-run", "--gpus", "8", "--frames", "11", "--steps", "2"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and json.loads(out.stdout.strip().splitlines()[-1])["frames"] == 22
+
+
+def test_runner_dry_run_a_failing_rank_does_not_strand_the_others(runner):
+    """One rank failing before the collective: every rank still reaches the barrier, nobody enters the gather, the process ends with
+    exit code 1 and no JSON line (instead of hanging in an all-gather that one member never joins)."""
+    out = subprocess.run([runner, "--dry-run", "--gpus", "8", "--steps", "3", "--dry-fail", "5"], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 1 and "gpu 5" in out.stderr and not [l for l in out.stdout.splitlines() if l.startswith("{")]
+    # a plan the library refuses (packed fp16 with colour stages is caught by the option parser; an unusable ratio by the plan)
+    out = subprocess.run([runner, "--dry-run", "--gpus", "2", "--in", "640x640", "--out", "10x10", "--steps", "1"], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 1 and "fsr1_upscale_plan" in out.stderr
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("pipeline", ["two-pass", "fused", "easu", "auto"])
 def test_runner_on_gpu(runner, pipeline):
