@@ -22,7 +22,9 @@ hipError_t fused_h_launch(const FusedArgs& a, hipStream_t stream);
 hipError_t fused_s2_launch(const FusedArgs& a, int fmt, bool exact, hipStream_t stream);
 size_t fused_s2_lds_bytes(int fmt);
 void fused_s2_geometry(int width, int height, int steps, int* tiles_x, int* tiles_y);
-int fused_s2_run_steps(int width, int height, int frames, int cus);
+int fused_s2_run_steps(int width, int height, int frames, int cus, int wgs_per_cu);
+hipError_t fused_s2_h_launch(const FusedArgs& a, hipStream_t stream);
+size_t fused_s2_h_lds_bytes();
 void fused_s2_force_steps(int steps);
 size_t fused_h_lds_bytes(int fp_w, int fp_h);
 hipError_t easu_h_launch(const EasuArgs& a, bool s2, hipStream_t stream);
@@ -502,15 +504,16 @@ static int fused_dispatch_impl(const fsr1_image* in, const fsr1_image* out, cons
   a.frames = out->frames;
   // Exact 2x (con0 = {1/2, 1/2, -1/4, -1/4}), plain F arithmetic, a whole image or a band from an even row: the variant whose lanes own 2x2 quads
   // of the apron tile (fsr1_fused_s2.hip); its tiles are 62 pixels wide and 2 QH - 2 tall.
+  // (packed fp16: the H twin, fsr1_fused_s2_h.hip — whole images only, five workgroups per CU)
   const bool s2 = easu_con[0] == 0x3f000000u && easu_con[1] == 0x3f000000u && easu_con[2] == 0xbe800000u && easu_con[3] == 0xbe800000u &&
-                  !(flags & FSR1_FLAG_NO_FAST_PATHS) && !packed && !a.color.stages && !(origin_y & 1) &&
-                  fused_s2_lds_bytes(in->format) <= 160 * 1024;
-  a.run_steps = s2 ? fused_s2_run_steps(out->width, out->height, out->frames, device_cus()) : 0;
+                  !(flags & FSR1_FLAG_NO_FAST_PATHS) && !a.color.stages && !(origin_y & 1) &&
+                  (packed ? origin_y == 0 && !rows_above && !rows_below : fused_s2_lds_bytes(in->format) <= 160 * 1024);
+  a.run_steps = s2 ? fused_s2_run_steps(out->width, out->height, out->frames, device_cus(), packed ? 5 : 7) : 0;
   if (s2) fused_s2_geometry(out->width, out->height, a.run_steps, &a.tiles_x, &a.tiles_y);
   if ((rc = check_grid("fused", a.tiles_x, a.tiles_y, a.frames))) return rc;
   a.flags = resolve_output_policy(flags, true);
   const bool exact = (flags & FSR1_FLAG_MATH_EXACT) != 0;
-  hipError_t e = packed ? fused_h_launch(a, static_cast<hipStream_t>(stream))
+  hipError_t e = packed ? (s2 ? fused_s2_h_launch(a, static_cast<hipStream_t>(stream)) : fused_h_launch(a, static_cast<hipStream_t>(stream)))
                  : a.color.stages ? fused_color_launch(a, in->format, out->format, exact, static_cast<hipStream_t>(stream))
                  : s2             ? fused_s2_launch(a, in->format, exact, static_cast<hipStream_t>(stream))
                                   : fused_launch(a, in->format, exact, static_cast<hipStream_t>(stream));

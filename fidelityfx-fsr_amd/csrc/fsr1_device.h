@@ -19,6 +19,10 @@ constexpr int kTileW = 64;
 constexpr int kTileH = 16;  // multiple of 4 (rows are split over the four waves); 8 / 12 / 24 / 32 measured slower at every ratio (profiles/ab_r02/c11_*)
 constexpr int kThreads = 256;
 constexpr int kFusedTileH = 16;  // output rows per fused-kernel tile (multiple of 4)
+// Exact-2x fused launch (fsr1_fused_s2.hip, fsr1_fused_s2_h.hip): a workgroup owns a 62-pixel column and walks down it in steps of
+// 16 EASU rows — 32 x 8 quads, one per lane — kept in an LDS ring of 18 rows (the 16 new ones and the last two of the step before).
+constexpr int kFs2OutW = 62, kFs2MidW = 64, kFs2FpW = 35;
+constexpr int kFs2QH = 8, kFs2FpH = kFs2QH + 3, kFs2Step = 2 * kFs2QH, kFs2Ring = kFs2Step + 2;  // quad rows, footprint rows, EASU rows per step, ring rows
 constexpr int kXcds = 8;  // MI355X: 8 XCDs, workgroup b is dispatched to XCD b % 8
 
 struct ColorPassArgs {

@@ -22,8 +22,7 @@
 
 namespace fsr1 {
 
-constexpr int kFs2OutW = 62, kFs2MidW = 64, kFs2FpW = 35;
-constexpr int kFs2QH = 8, kFs2FpH = kFs2QH + 3, kFs2Step = 2 * kFs2QH, kFs2Ring = kFs2Step + 2;  // quad rows, footprint rows, EASU rows per step, ring rows
+// (tile / step / ring geometry: kFs2* in fsr1_device.h, shared with the packed-fp16 twin fsr1_fused_s2_h.hip)
 
 size_t fused_s2_lds_bytes(int fmt) {
   const size_t texel = fmt == FSR1_FORMAT_RGBA32F ? 16 : (fmt == FSR1_FORMAT_RGBA16F ? 8 : 4);
@@ -40,10 +39,12 @@ constexpr int kFs2MaxSteps = 8;
 // the same image (tests/test_gpu_parity.py::test_fused_exact_2x_run_steps); tuning runs set it through the same call.
 static std::atomic<int> g_fs2_forced_steps{0};
 void fused_s2_force_steps(int steps) { g_fs2_forced_steps.store(steps < 0 ? 0 : (steps > 64 ? 64 : steps), std::memory_order_relaxed); }
-int fused_s2_run_steps(int width, int height, int frames, int cus) {
+int fused_s2_run_steps(int width, int height, int frames, int cus, int wgs_per_cu) {
   if (const int forced = g_fs2_forced_steps.load(std::memory_order_relaxed); forced > 0) return forced;
   const long long tiles1 = (long long)((width + kFs2OutW - 1) / kFs2OutW) * ((height + kFs2Step - 3) / (kFs2Step - 2)) * frames;
-  const long long s = tiles1 / (5ll * (cus > 0 ? cus : 256) * 7);  // (cus: the device's compute units — 256 on MI355X, where the rule was measured)
+  // (cus: the device's compute units — 256 on MI355X, where the rule was measured; wgs_per_cu: what the kernel's LDS admits, 7 for
+  //  the F kernel, 5 for the packed-fp16 one)
+  const long long s = tiles1 / (5ll * (cus > 0 ? cus : 256) * (wgs_per_cu > 0 ? wgs_per_cu : 7));
   return (int)(s < 1 ? 1 : s > kFs2MaxSteps ? kFs2MaxSteps : s);
 }
 

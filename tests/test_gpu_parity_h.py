@@ -230,6 +230,38 @@ def test_fused_h_equals_two_pass_h(fsr, shape):
         assert torch.equal(one.view(torch.int16), two.view(torch.int16)), "fused H differs from two-pass H (opts %d)" % opts
 
 
+@pytest.mark.parametrize("steps", [0, 1, 2, 3, 5, 9])
+@pytest.mark.parametrize("shape", [(97, 160), (31, 75), (64, 40), (70, 9), (1, 1)], ids=lambda s: "%dx%d" % s)
+def test_fused_h_exact_2x_walk_equals_two_pass_h(fsr, shape, steps):
+    """The exact-2x single-launch H pipeline (fsr1_fused_s2_h.hip: a quad per lane, 62-pixel columns walked in 16-row steps through an
+    18-row LDS ring, two vertically adjacent pixels per packed RCAS evaluation) against the two H dispatches and against the generic
+    fused H kernel (FSR1_FLAG_NO_FAST_PATHS), bit for bit: every RCAS option, batches with pitches, any number of steps per run
+    (0 = the host's rule; 9 takes the ring through all of its positions)."""
+    iw, ih = shape
+    ow, oh = 2 * iw, 2 * ih
+    n = 2
+    h = fsr.FLAG_MATH_PACKED_FP16
+    src = dev(np.stack([frames.synthetic_frame(iw, ih, k=50 + f, dtype=np.float16) for f in range(n)]))
+    fsr.load().fsr1_debug_fused_run_steps(steps)
+    try:
+        for opts in (0, fsr.FLAG_RCAS_DENOISE | fsr.FLAG_RCAS_PASSTHROUGH_ALPHA, fsr.FLAG_HDR_SQUARE):
+            mid = torch.zeros(n, oh, ow, 4, dtype=torch.float16, device="cuda")
+            two = torch.zeros_like(mid)
+            fsr.easu(src, mid, flags=h)
+            fsr.rcas(mid, two, sharpness=0.3, flags=h | opts)
+            big_out = torch.full((n, oh + 1, ow + 5, 4), 7, dtype=torch.float16, device="cuda")
+            dst = big_out[:, :oh, :ow]
+            fsr.easu_rcas_fused(src, dst, sharpness=0.3, flags=h | opts)
+            torch.cuda.synchronize()
+            assert bool((big_out[:, oh:] == 7).all()) and bool((big_out[:, :, ow:] == 7).all()), "wrote outside the output view"
+            assert torch.equal(dst.view(torch.int16), two.view(torch.int16)), "steps %d != two H dispatches (opts %d)" % (steps, opts)
+            gen = torch.zeros_like(two)
+            fsr.easu_rcas_fused(src, gen, sharpness=0.3, flags=h | opts | fsr.FLAG_NO_FAST_PATHS)
+            assert torch.equal(gen.view(torch.int16), two.view(torch.int16)), "generic fused H != two H dispatches (opts %d)" % opts
+    finally:
+        fsr.load().fsr1_debug_fused_run_steps(0)
+
+
 def test_fused_h_batch_with_pitches(fsr):
     n, iw, ih, ow, oh = 3, 70, 37, 140, 74
     big_in = torch.zeros(n, ih + 2, iw + 3, 4, dtype=torch.float16, device="cuda")
