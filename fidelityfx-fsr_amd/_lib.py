@@ -79,6 +79,7 @@ SYMBOLS = {
     "fsr1_device_count": (ctypes.c_int, []),
     "fsr1_selftest": (ctypes.c_int, [_U32P]),
     "fsr1_debug_fused_run_steps": (None, [ctypes.c_int32]),
+    "fsr1_debug_fused_tall_tiles": (None, [ctypes.c_int32]),
     "fsr1_timer_create": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p)]),
     "fsr1_timer_start": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     "fsr1_timer_stop": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
@@ -138,6 +139,8 @@ def load():
         forced = os.environ.get("FSR1_FUSED_S2_STEPS")  # tuning runs (tools/abtest.py `lib%FSR1_FUSED_S2_STEPS=n`): the library itself reads no environment
         if forced:
             lib.fsr1_debug_fused_run_steps(int(forced))
+        if os.environ.get("FSR1_FUSED_S2_TALL"):  # -1 / 0 / 1, tuning runs only
+            lib.fsr1_debug_fused_tall_tiles(int(os.environ["FSR1_FUSED_S2_TALL"]))
     return _lib
 
 

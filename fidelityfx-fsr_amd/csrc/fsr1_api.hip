@@ -19,13 +19,15 @@ void rcas_geometry(int width, int height, int frames, int* tiles_x, int* tiles_y
 hipError_t fused_launch(const FusedArgs& a, int fmt, bool exact, hipStream_t stream);
 size_t fused_lds_bytes(int fmt, int fp_w, int fp_h);
 hipError_t fused_h_launch(const FusedArgs& a, hipStream_t stream);
-hipError_t fused_s2_launch(const FusedArgs& a, int fmt, bool exact, hipStream_t stream);
-size_t fused_s2_lds_bytes(int fmt);
-void fused_s2_geometry(int width, int height, int steps, int* tiles_x, int* tiles_y);
+hipError_t fused_s2_launch(const FusedArgs& a, int fmt, bool exact, bool tall, hipStream_t stream);
+size_t fused_s2_lds_bytes(int fmt, int waves);
+bool fused_s2_tall_tiles(int width, int height, int frames, int steps, int cus, int fmt);
+void fused_s2_geometry(int width, int height, int steps, int* tiles_x, int* tiles_y, int step_rows);
 int fused_s2_run_steps(int width, int height, int frames, int cus, int wgs_per_cu);
 hipError_t fused_s2_h_launch(const FusedArgs& a, hipStream_t stream);
 size_t fused_s2_h_lds_bytes();
 void fused_s2_force_steps(int steps);
+void fused_s2_force_tall(int mode);
 size_t fused_h_lds_bytes(int fp_w, int fp_h);
 hipError_t easu_h_launch(const EasuArgs& a, bool s2, hipStream_t stream);
 hipError_t easu_color_launch(const EasuArgs& a, int fin, int fout, bool exact, hipStream_t stream);
@@ -507,15 +509,16 @@ static int fused_dispatch_impl(const fsr1_image* in, const fsr1_image* out, cons
   // (packed fp16: the H twin, fsr1_fused_s2_h.hip — whole images only, five workgroups per CU)
   const bool s2 = easu_con[0] == 0x3f000000u && easu_con[1] == 0x3f000000u && easu_con[2] == 0xbe800000u && easu_con[3] == 0xbe800000u &&
                   !(flags & FSR1_FLAG_NO_FAST_PATHS) && !a.color.stages && !(origin_y & 1) &&
-                  (packed ? origin_y == 0 && !rows_above && !rows_below : fused_s2_lds_bytes(in->format) <= 160 * 1024);
+                  (packed ? origin_y == 0 && !rows_above && !rows_below : fused_s2_lds_bytes(in->format, 4) <= 160 * 1024);
   a.run_steps = s2 ? fused_s2_run_steps(out->width, out->height, out->frames, device_cus(), packed ? 5 : 7) : 0;
-  if (s2) fused_s2_geometry(out->width, out->height, a.run_steps, &a.tiles_x, &a.tiles_y);
+  const bool tall = s2 && !packed && fused_s2_tall_tiles(out->width, out->height, out->frames, a.run_steps, device_cus(), in->format);
+  if (s2) fused_s2_geometry(out->width, out->height, a.run_steps, &a.tiles_x, &a.tiles_y, tall ? 2 * kFs2Step : kFs2Step);
   if ((rc = check_grid("fused", a.tiles_x, a.tiles_y, a.frames))) return rc;
   a.flags = resolve_output_policy(flags, true);
   const bool exact = (flags & FSR1_FLAG_MATH_EXACT) != 0;
   hipError_t e = packed ? (s2 ? fused_s2_h_launch(a, static_cast<hipStream_t>(stream)) : fused_h_launch(a, static_cast<hipStream_t>(stream)))
                  : a.color.stages ? fused_color_launch(a, in->format, out->format, exact, static_cast<hipStream_t>(stream))
-                 : s2             ? fused_s2_launch(a, in->format, exact, static_cast<hipStream_t>(stream))
+                 : s2             ? fused_s2_launch(a, in->format, exact, tall, static_cast<hipStream_t>(stream))
                                   : fused_launch(a, in->format, exact, static_cast<hipStream_t>(stream));
   if (e != hipSuccess) return hip_fail(e, "fused launch");
   return FSR1_OK;
@@ -666,6 +669,8 @@ int fsr1_upscale_plan(const fsr1_image* in, int32_t have_intermediary, const fsr
 
 // Test hook: force the number of 16-row steps the exact-2x fused launch's workgroups walk (0 = the host's rule).
 void fsr1_debug_fused_run_steps(int32_t steps) { fused_s2_force_steps(steps); }
+// Test hook: -1 = the host's rule, 0 = never, 1 = always take the 512-thread tall tile for one-step exact-2x fused launches.
+void fsr1_debug_fused_tall_tiles(int32_t mode) { fused_s2_force_tall(mode); }
 
 int fsr1_selftest(uint32_t* failures) {
   if (!failures) return fail(FSR1_ERR_INVALID_ARGUMENT, "selftest: null");

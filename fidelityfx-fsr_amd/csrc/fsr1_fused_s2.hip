@@ -24,9 +24,11 @@ namespace fsr1 {
 
 // (tile / step / ring geometry: kFs2* in fsr1_device.h, shared with the packed-fp16 twin fsr1_fused_s2_h.hip)
 
-size_t fused_s2_lds_bytes(int fmt) {
+// `waves`: 4 = the 256-thread workgroup (16 EASU rows per step), 8 = the 512-thread one (32 rows per step: the one-step launch of
+// a single large frame, see fused_s2_tall_tiles)
+size_t fused_s2_lds_bytes(int fmt, int waves) {
   const size_t texel = fmt == FSR1_FORMAT_RGBA32F ? 16 : (fmt == FSR1_FORMAT_RGBA16F ? 8 : 4);
-  return easu_lds_region_bytes((size_t)kFs2FpW * kFs2FpH) + (size_t)kFs2MidW * kFs2Ring * texel;
+  return easu_lds_region_bytes((size_t)kFs2FpW * (2 * waves + 3)) + (size_t)kFs2MidW * (4 * waves + 2) * texel;
 }
 
 // Steps per run: one workgroup per (column, run).  With S steps a run wastes 2 of 16 S EASU rows, so S wants to be large; but a
@@ -48,17 +50,36 @@ int fused_s2_run_steps(int width, int height, int frames, int cus, int wgs_per_c
   return (int)(s < 1 ? 1 : s > kFs2MaxSteps ? kFs2MaxSteps : s);
 }
 
-void fused_s2_geometry(int width, int height, int steps, int* tiles_x, int* tiles_y) {
-  const int run = kFs2Step * steps - 2;
+// One-step launches of a frame that fills the chip take the TALL tile: a 512-thread workgroup (8 waves) whose single step is 32 EASU
+// rows for 30 output rows — the vertical apron 2 of 32 rows instead of 2 of 16 (EASU work -6.7 %) with no serial steps, which is what
+// makes walking lose on one frame (profiles/ab_r04/r4c1_fused_trace.log: a launch's first residency runs its steps in lock-step and
+// its tail is as long as a run).  Three workgroups of eight waves per CU (38.7 KB of LDS each).  Small frames keep the 256-thread
+// tile: twice as many workgroups to spread over the CUs.
+static std::atomic<int> g_fs2_forced_tall{-1};  // test hook (fsr1_debug_fused_tall_tiles): -1 = the rule, 0 = never, 1 = whenever the launch is one-step
+void fused_s2_force_tall(int mode) { g_fs2_forced_tall.store(mode < 0 ? -1 : (mode ? 1 : 0), std::memory_order_relaxed); }
+bool fused_s2_tall_tiles(int width, int height, int frames, int steps, int cus, int fmt) {
+  if (steps != 1 || fmt == FSR1_FORMAT_RGBA32F) return false;
+  if (const int forced = g_fs2_forced_tall.load(std::memory_order_relaxed); forced >= 0) return forced != 0;
+  const long long tall = (long long)((width + kFs2OutW - 1) / kFs2OutW) * ((height + 29) / 30) * frames;
+  return tall >= 4ll * 3 * (cus > 0 ? cus : 256);  // at least four residencies of tall tiles
+}
+
+void fused_s2_geometry(int width, int height, int steps, int* tiles_x, int* tiles_y, int step_rows) {
+  const int run = step_rows * steps - 2;
   *tiles_x = (width + kFs2OutW - 1) / kFs2OutW;
   *tiles_y = (height + run - 1) / run;
 }
 
 // RUN = false: the one-step launch (run_steps == 1), compiled without the step loop and the ring arithmetic.
-template <int FMT, bool EXACT, bool RUN>
-__global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(7, 8))) fused_s2_kernel(const FusedArgs a) {  // (<= 72 VGPRs: 7 workgroups per CU is what its LDS admits)
+// WAVES: 4 (256 threads, 32 x 8 quads, 16 EASU rows per step) or 8 (512 threads, 32 x 16 quads, 32 rows per step).
+// (register budget: <= 72 VGPRs for seven 4-wave workgroups per CU, which is what their LDS admits; the 8-wave workgroup's LDS admits
+//  three per CU = six waves per SIMD: <= 80)
+template <int FMT, bool EXACT, bool RUN, int WAVES>
+__global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(WAVES == 4 ? 7 : 6, 8))) fused_s2_kernel(const FusedArgs a) {
   typedef typename Pixel<FMT>::T texel_t;
-  static_assert(kFs2QH == 8 && kThreads == 256, "32 x 8 quads over 256 lanes");
+  static_assert(WAVES == 4 || WAVES == 8, "a wave filters two quad rows = four EASU rows of a step");
+  constexpr int kFs2FpH = 2 * WAVES + 3, kFs2Step = 4 * WAVES, kFs2Ring = kFs2Step + 2;  // footprint rows, EASU rows per step, ring rows (shadow the 4-wave constants)
+  constexpr int kThreads = 64 * WAVES;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   EasuLds l = easu_lds_carve(smem, kFs2FpW * kFs2FpH);
   texel_t* const mid = reinterpret_cast<texel_t*>(smem + easu_lds_region_bytes(kFs2FpW * kFs2FpH));  // [kFs2Ring][64], a ring of rows
@@ -98,8 +119,8 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(7
     int tid = threadIdx.x;
     if (RUN) asm volatile("" : "+v"(tid));  // per-lane addresses are re-derived in every step rather than kept in registers across the filter
     const int lane = tid & 63;
-    easu_stage_footprint<FMT, false, EXACT, kFs2FpW, kFs2FpH>(l, a.in, in_frame, 31 * tx - 2, ((ay0 + 1) >> 1) - 2 + (a.origin_y >> 1), kFs2FpW,
-                                                             kFs2FpH, tid);
+    easu_stage_footprint<FMT, false, EXACT, kFs2FpW, kFs2FpH, kThreads>(l, a.in, in_frame, 31 * tx - 2, ((ay0 + 1) >> 1) - 2 + (a.origin_y >> 1), kFs2FpW,
+                                                                       kFs2FpH, tid);
     // (its two barriers also separate this step's ring writes from the previous step's RCAS reads)
 
     // ---- phase 3: EASU on the step's 64 x 16 pixels, a quad per lane, rounded to the storage format (EASU runs with
@@ -182,19 +203,23 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(7
   }
 }
 
-template <int FMT, bool EXACT, bool RUN>
+template <int FMT, bool EXACT, bool RUN, int WAVES>
 static hipError_t fused_s2_launch_one(const FusedArgs& a, hipStream_t stream) {
-  const dim3 grid((unsigned)(a.tiles_x * a.tiles_y * a.frames)), block(kThreads);
-  const size_t lds = fused_s2_lds_bytes(FMT);
-  if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&fused_s2_kernel<FMT, EXACT, RUN>), lds); e != hipSuccess) return e;
-  hipLaunchKernelGGL((fused_s2_kernel<FMT, EXACT, RUN>), grid, block, lds, stream, a);
+  const dim3 grid((unsigned)(a.tiles_x * a.tiles_y * a.frames)), block(64 * WAVES);
+  const size_t lds = fused_s2_lds_bytes(FMT, WAVES);
+  if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&fused_s2_kernel<FMT, EXACT, RUN, WAVES>), lds); e != hipSuccess) return e;
+  hipLaunchKernelGGL((fused_s2_kernel<FMT, EXACT, RUN, WAVES>), grid, block, lds, stream, a);
   return hipGetLastError();
 }
 
-hipError_t fused_s2_launch(const FusedArgs& a, int fmt, bool exact, hipStream_t stream) {
-#define FSR1_LAUNCH_E(F)                                                                                                         \
-  return a.run_steps > 1 ? (exact ? fused_s2_launch_one<F, true, true>(a, stream) : fused_s2_launch_one<F, false, true>(a, stream)) \
-                         : (exact ? fused_s2_launch_one<F, true, false>(a, stream) : fused_s2_launch_one<F, false, false>(a, stream))
+// tall: the 512-thread workgroup (one-step launches only: the host pairs it with run_steps == 1)
+hipError_t fused_s2_launch(const FusedArgs& a, int fmt, bool exact, bool tall, hipStream_t stream) {
+#define FSR1_LAUNCH_E(F)                                                                                                                  \
+  if (tall && F != FSR1_FORMAT_RGBA32F)                                                                                                   \
+    return exact ? fused_s2_launch_one<F == FSR1_FORMAT_RGBA32F ? FSR1_FORMAT_RGBA16F : F, true, false, 8>(a, stream)                     \
+                 : fused_s2_launch_one<F == FSR1_FORMAT_RGBA32F ? FSR1_FORMAT_RGBA16F : F, false, false, 8>(a, stream);                   \
+  return a.run_steps > 1 ? (exact ? fused_s2_launch_one<F, true, true, 4>(a, stream) : fused_s2_launch_one<F, false, true, 4>(a, stream)) \
+                         : (exact ? fused_s2_launch_one<F, true, false, 4>(a, stream) : fused_s2_launch_one<F, false, false, 4>(a, stream))
   switch (fmt) {
     case FSR1_FORMAT_RGBA16F: FSR1_LAUNCH_E(FSR1_FORMAT_RGBA16F);
     case FSR1_FORMAT_RGBA32F: FSR1_LAUNCH_E(FSR1_FORMAT_RGBA32F);

@@ -287,6 +287,9 @@ int fsr1_selftest(uint32_t* failures);
  * fused launch walk down their columns (fsr1_fused_s2.hip), clamped to 0 .. 64; 0 restores the host's rule.  Every value gives
  * the same image, bit for bit — which is what tests/test_gpu_parity.py::test_fused_exact_2x_run_steps uses it to show. */
 void fsr1_debug_fused_run_steps(int32_t steps);
+/* ... and the tile shape of its one-step launches: -1 = the host's rule (the 62 x 30 tile of a 512-thread workgroup for frames that
+ * fill the chip, the 62 x 14 tile of a 256-thread one otherwise), 0 = never the tall tile, 1 = always.  Same image either way. */
+void fsr1_debug_fused_tall_tiles(int32_t mode);
 
 /* HIP-event stopwatch on a caller stream (used by the bench so that kernel time is measured on the
  * very stream the kernels run on).  Handles are opaque. */

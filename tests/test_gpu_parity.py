@@ -626,3 +626,45 @@ def test_fused_exact_2x_run_steps(fsr, shape, steps):
             assert torch.equal(band.view(torch.int16), two[0].view(torch.int16)), "bands at steps %d != two dispatches (flags %d)" % (steps, flags)
         finally:
             fsr.load().fsr1_debug_fused_run_steps(0)
+
+
+@pytest.mark.parametrize("shape", [(97, 160), (31, 75), (64, 40), (70, 9), (1, 1), (200, 31)], ids=lambda s: "%dx%d" % s)
+def test_fused_exact_2x_tall_tiles(fsr, shape):
+    """The one-step exact-2x fused launch of a frame that fills the chip runs 512-thread workgroups on 62 x 30 tiles (32 EASU rows per
+    step, fsr1_fused_s2.hip WAVES = 8).  Forced here on small ragged images, batches, UNORM storage and row bands: the image is the
+    two dispatches', bit for bit."""
+    iw, ih = shape
+    ow, oh = 2 * iw, 2 * ih
+    n = 2
+    src = dev(np.stack([frames.synthetic_frame(iw, ih, k=60 + f, dtype=np.float16) for f in range(n)]))
+    lib = fsr.load()
+    lib.fsr1_debug_fused_tall_tiles(1)
+    try:
+        for flags in (0, fsr.FLAG_MATH_EXACT | fsr.FLAG_RCAS_DENOISE, fsr.FLAG_RCAS_PASSTHROUGH_ALPHA | fsr.FLAG_HDR_SQUARE):
+            mid = torch.zeros(n, oh, ow, 4, dtype=torch.float16, device="cuda")
+            two = torch.zeros_like(mid)
+            fsr.easu(src, mid, flags=flags & fsr.FLAG_MATH_EXACT)
+            fsr.rcas(mid, two, sharpness=0.3, flags=flags)
+            big_out = torch.full((n, oh + 1, ow + 5, 4), 7, dtype=torch.float16, device="cuda")
+            dst = big_out[:, :oh, :ow]
+            fsr.easu_rcas_fused(src, dst, sharpness=0.3, flags=flags)
+            torch.cuda.synchronize()
+            assert bool((big_out[:, oh:] == 7).all()) and bool((big_out[:, :, ow:] == 7).all()), "wrote outside the output view"
+            assert torch.equal(dst.view(torch.int16), two.view(torch.int16)), "tall tiles != two dispatches (flags %d)" % flags
+            band = torch.full_like(two[0], -1.0)
+            cuts = [0, (oh // 3) & ~1, (2 * oh // 3) & ~1, oh]
+            for y0, y1 in zip(cuts, cuts[1:]):
+                if y1 > y0:
+                    fsr.upscale_band(src[0], band[y0:y1], (ow, oh), (y0, y1), sharpness=0.3, flags=flags, fused=True)
+            assert torch.equal(band.view(torch.int16), two[0].view(torch.int16)), "bands with tall tiles != two dispatches (flags %d)" % flags
+        # RGBA8 storage
+        src8 = (src.float().clamp(0, 1) * 255 + 0.5).to(torch.uint8)
+        mid8 = torch.zeros(n, oh, ow, 4, dtype=torch.uint8, device="cuda")
+        two8 = torch.zeros_like(mid8)
+        one8 = torch.zeros_like(mid8)
+        fsr.easu(src8, mid8)
+        fsr.rcas(mid8, two8, sharpness=0.3)
+        fsr.easu_rcas_fused(src8, one8, sharpness=0.3)
+        assert torch.equal(one8, two8)
+    finally:
+        lib.fsr1_debug_fused_tall_tiles(-1)
