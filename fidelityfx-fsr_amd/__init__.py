@@ -6,7 +6,7 @@ repository root.
 """
 from . import _lib, frames  # noqa: F401
 from .api import *  # noqa: F401,F403
-from .api import FSR_Filter, State, Timer  # noqa: F401
+from .api import FSR_Filter, Pipeline, State, Timer  # noqa: F401
 from .shard import frames_for_rank  # noqa: F401
 
 build = _lib.build

@@ -74,6 +74,14 @@ SYMBOLS = {
     "fsr1_upscale": (ctypes.c_int, [ctypes.POINTER(fsr1_image)] * 3 + [ctypes.POINTER(fsr1_params), ctypes.c_void_p]),
     "fsr1_upscale_ex": (ctypes.c_int, [_IMG] * 3 + [ctypes.POINTER(fsr1_params), _STG, ctypes.c_void_p]),
     "fsr1_upscale_plan": (ctypes.c_int, [_IMG, ctypes.c_int32, _IMG, ctypes.POINTER(fsr1_params), ctypes.c_int32]),
+    "fsr1_pipeline_create": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int32]),
+    "fsr1_pipeline_upscale": (ctypes.c_int, [ctypes.c_void_p, _IMG, _IMG, ctypes.POINTER(fsr1_params), _STG]),
+    "fsr1_pipeline_fork": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
+    "fsr1_pipeline_join": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
+    "fsr1_pipeline_synchronize": (ctypes.c_int, [ctypes.c_void_p]),
+    "fsr1_pipeline_streams": (ctypes.c_int32, [ctypes.c_void_p]),
+    "fsr1_pipeline_stream": (ctypes.c_void_p, [ctypes.c_void_p, ctypes.c_int32]),
+    "fsr1_pipeline_destroy": (ctypes.c_int, [ctypes.c_void_p]),
     "fsr1_last_error": (ctypes.c_char_p, []),
     "fsr1_version": (ctypes.c_int, []),
     "fsr1_device_count": (ctypes.c_int, []),

@@ -357,6 +357,48 @@ class FSR_Filter:
         return self._output
 
 
+class Pipeline:
+    """fsr1_pipeline: independent frames on alternating HIP streams (include/fsr1_hip.h, "Frame pipeline").  Frame i of a sequence
+    of upscale() calls runs on stream i mod `streams` with that stream's own EASU -> RCAS intermediary, so the tail of one frame
+    overlaps the head of the next (a kernel boundary costs ~5 us on MI355X).  The tensors of calls that may overlap — the last
+    `streams` — must not alias; fork() / join() order the pipeline against a torch stream (default: the current one)."""
+
+    def __init__(self, streams=2):
+        self._h = ctypes.c_void_p()
+        _lib.check(_lib.load().fsr1_pipeline_create(ctypes.byref(self._h), int(streams)))
+        self.streams = int(streams)
+
+    def upscale(self, src, dst, sharpness=0.25, use_rcas=True, fused=0, flags=0, hdr=False, stages=None, render_size=None):
+        """dst = Upscale(src) (FSR_Filter::Upscale, FSR_Filter.cpp:101-141) on the pipeline's next stream; fused: 0 two dispatches, 1 the
+        single launch, 2 whichever is faster; render_size: (renderWidth, renderHeight) when smaller than the input resource."""
+        i, o = image_of(src), image_of(dst)
+        rw, rh = render_size if render_size is not None else (i.width, i.height)
+        p = fsr1_params(float(rw), float(rh), int(bool(use_rcas)), float(sharpness), int(bool(hdr)), int(fused) if use_rcas else 0, int(flags))
+        sp, _keep = _stages(stages)
+        _lib.check(_lib.load().fsr1_pipeline_upscale(self._h, ctypes.byref(i), ctypes.byref(o), ctypes.byref(p), sp))
+        return dst
+
+    def fork(self, stream=None):
+        _lib.check(_lib.load().fsr1_pipeline_fork(self._h, _stream_ptr(stream)))
+
+    def join(self, stream=None):
+        _lib.check(_lib.load().fsr1_pipeline_join(self._h, _stream_ptr(stream)))
+
+    def synchronize(self):
+        _lib.check(_lib.load().fsr1_pipeline_synchronize(self._h))
+
+    def close(self):
+        if self._h:
+            _lib.load().fsr1_pipeline_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def selftest():
     """Number of binary16 operands (of 65536) for which the packed-fp16 kernels' reciprocal is not the
     correctly rounded 1/x; 0 on a conforming device."""

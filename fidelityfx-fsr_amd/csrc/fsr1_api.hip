@@ -689,6 +689,110 @@ int fsr1_selftest(uint32_t* failures) {
   return FSR1_OK;
 }
 
+// ---- frame pipeline: independent frames on alternating HIP streams (include/fsr1_hip.h) ----
+struct fsr1_pipeline {
+  static constexpr int kMax = 8;
+  int n = 0, next = 0, device = 0;
+  hipStream_t streams[kMax] = {};
+  hipEvent_t done[kMax] = {};   // recorded after a slot's latest submission (join)
+  hipEvent_t fork_ev = nullptr;
+  void* mid[kMax] = {};         // per-slot EASU -> RCAS intermediary, tightly packed, grown on demand
+  size_t mid_bytes[kMax] = {};
+};
+
+int fsr1_pipeline_create(fsr1_pipeline** out, int32_t streams) {
+  if (!out) return fail(FSR1_ERR_INVALID_ARGUMENT, "pipeline_create: null");
+  if (streams < 1 || streams > fsr1_pipeline::kMax) return fail(FSR1_ERR_INVALID_ARGUMENT, "pipeline_create: streams must be 1 .. %d", fsr1_pipeline::kMax);
+  fsr1_pipeline* p = new fsr1_pipeline;
+  hipError_t e = hipGetDevice(&p->device);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&p->fork_ev, hipEventDisableTiming);
+  for (int i = 0; i < streams && e == hipSuccess; ++i) {
+    e = hipStreamCreateWithFlags(&p->streams[i], hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&p->done[i], hipEventDisableTiming);
+    if (e == hipSuccess) p->n = i + 1;
+  }
+  if (e != hipSuccess) {
+    const int rc = hip_fail(e, "pipeline_create");
+    (void)fsr1_pipeline_destroy(p);
+    return rc;
+  }
+  *out = p;
+  return FSR1_OK;
+}
+
+int fsr1_pipeline_upscale(fsr1_pipeline* p, const fsr1_image* in, const fsr1_image* out, const fsr1_params* params,
+                          const fsr1_color_stages* stages) {
+  if (!p || p->n < 1) return fail(FSR1_ERR_INVALID_ARGUMENT, "pipeline_upscale: null pipeline");
+  if (stages && !stages->stages) stages = nullptr;
+  UpscalePlan plan;
+  if (int rc = upscale_decide("pipeline_upscale", in, true, out, params, stages != nullptr, &plan)) return rc;
+  const int slot = p->next;
+  fsr1_image mid_img;
+  const fsr1_image* mid_p = nullptr;
+  if (plan.pipeline == 0) {  // two dispatches: this slot's own intermediary, out's format and extent
+    const size_t need = (size_t)out->width * pixel_bytes(out->format) * (size_t)out->height * (size_t)out->frames;
+    if (p->mid_bytes[slot] < need) {
+      if (p->mid[slot]) {
+        if (hipError_t e = hipStreamSynchronize(p->streams[slot]); e != hipSuccess) return hip_fail(e, "pipeline_upscale: hipStreamSynchronize");
+        (void)hipFree(p->mid[slot]);
+        p->mid[slot] = nullptr;
+        p->mid_bytes[slot] = 0;
+      }
+      if (hipError_t e = hipMalloc(&p->mid[slot], need); e != hipSuccess) return hip_fail(e, "pipeline_upscale: hipMalloc of the intermediary");
+      p->mid_bytes[slot] = need;
+    }
+    mid_img = fsr1_image{p->mid[slot], out->width, out->height, out->format, out->frames, 0, 0};
+    mid_p = &mid_img;
+  }
+  // (the plan is re-derived by fsr1_upscale_ex from the same arguments: `auto` with an intermediary on offer decides as it did above)
+  fsr1_params prm = *params;
+  if (plan.pipeline == 1) prm.fused = 1;                         // what was decided, whatever `auto` would say without an intermediary
+  else if (plan.pipeline == 0) prm.fused = 0;
+  if (int rc = fsr1_upscale_ex(in, mid_p, out, &prm, stages, p->streams[slot])) return rc;
+  if (hipError_t e = hipEventRecord(p->done[slot], p->streams[slot]); e != hipSuccess) return hip_fail(e, "pipeline_upscale: hipEventRecord");
+  p->next = (slot + 1) % p->n;
+  return FSR1_OK;
+}
+
+int fsr1_pipeline_fork(fsr1_pipeline* p, void* stream) {
+  if (!p) return fail(FSR1_ERR_INVALID_ARGUMENT, "pipeline_fork: null pipeline");
+  hipError_t e = hipEventRecord(p->fork_ev, static_cast<hipStream_t>(stream));
+  for (int i = 0; i < p->n && e == hipSuccess; ++i) e = hipStreamWaitEvent(p->streams[i], p->fork_ev, 0);
+  return e == hipSuccess ? FSR1_OK : hip_fail(e, "pipeline_fork");
+}
+
+int fsr1_pipeline_join(fsr1_pipeline* p, void* stream) {
+  if (!p) return fail(FSR1_ERR_INVALID_ARGUMENT, "pipeline_join: null pipeline");
+  hipError_t e = hipSuccess;
+  for (int i = 0; i < p->n && e == hipSuccess; ++i) {
+    e = hipEventRecord(p->done[i], p->streams[i]);
+    if (e == hipSuccess) e = hipStreamWaitEvent(static_cast<hipStream_t>(stream), p->done[i], 0);
+  }
+  return e == hipSuccess ? FSR1_OK : hip_fail(e, "pipeline_join");
+}
+
+int fsr1_pipeline_synchronize(fsr1_pipeline* p) {
+  if (!p) return fail(FSR1_ERR_INVALID_ARGUMENT, "pipeline_synchronize: null pipeline");
+  for (int i = 0; i < p->n; ++i)
+    if (hipError_t e = hipStreamSynchronize(p->streams[i]); e != hipSuccess) return hip_fail(e, "pipeline_synchronize");
+  return FSR1_OK;
+}
+
+int fsr1_pipeline_streams(const fsr1_pipeline* p) { return p ? p->n : 0; }
+void* fsr1_pipeline_stream(const fsr1_pipeline* p, int32_t i) { return p && i >= 0 && i < p->n ? p->streams[i] : nullptr; }
+
+int fsr1_pipeline_destroy(fsr1_pipeline* p) {
+  if (!p) return FSR1_OK;
+  for (int i = 0; i < fsr1_pipeline::kMax; ++i) {
+    if (p->streams[i]) { (void)hipStreamSynchronize(p->streams[i]); (void)hipStreamDestroy(p->streams[i]); }
+    if (p->done[i]) (void)hipEventDestroy(p->done[i]);
+    if (p->mid[i]) (void)hipFree(p->mid[i]);
+  }
+  if (p->fork_ev) (void)hipEventDestroy(p->fork_ev);
+  delete p;
+  return FSR1_OK;
+}
+
 // ---- HIP-event stopwatch ----
 struct fsr1_timer {
   hipEvent_t start, stop;

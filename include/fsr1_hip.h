@@ -269,6 +269,36 @@ int fsr1_upscale_plan(const fsr1_image* in, int32_t have_intermediary, const fsr
                       int32_t have_stages);
 
 /* ------------------------------------------------------------------------------------------------
+ * Frame pipeline: independent frames on alternating HIP streams.
+ *
+ * FSR 1.0 keeps no history, so consecutive frames of a stream are independent — but dispatches on ONE HIP stream serialise,
+ * and every kernel boundary costs the chip about 5 us in which it computes nothing (the last workgroups drain, caches write
+ * back, the next dispatch ramps up; measured on MI355X, profiles/ab_r04/r4c1_fused_trace.log: a fused 4K launch is 59.6 us
+ * from first to last instruction and 65 us per launch back to back).  A pipeline owns N non-blocking streams and N
+ * EASU -> RCAS intermediaries and sends frame i to stream i mod N: the tail of one frame overlaps the head of the next.
+ * Measured with N = 2 (r4c2_two_stream.log): 1080p -> 4K two dispatches 65.6 -> 60.2 us per frame, fused launch 60.5 -> 56.4,
+ * 1440p -> 4K 77.9 -> 70.7, 540p -> 1080p 25.8 -> 15.7; N = 3 adds nothing.  The reference's sample has one graphics queue and
+ * no counterpart; this is what its async-compute note (FSR_Filter.cpp:101 ff. run inside the frame's command list) leaves to
+ * the engine.  The images of submissions that may overlap (the last N) must not alias; a pipeline is driven by one host thread
+ * at a time.  fork / join order the pipeline's streams against a stream of the caller's.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct fsr1_pipeline fsr1_pipeline; /* opaque */
+int fsr1_pipeline_create(fsr1_pipeline** pipeline, int32_t streams /* 1 .. 8 */);
+/* fsr1_upscale_ex for one frame (or batch) on the pipeline's next stream, with that stream's own intermediary (allocated and
+ * grown on demand; params->fused = 2 decides as if an intermediary was supplied).  Asynchronous. */
+int fsr1_pipeline_upscale(fsr1_pipeline* pipeline, const fsr1_image* in, const fsr1_image* out, const fsr1_params* params,
+                          const fsr1_color_stages* stages);
+/* Work submitted to the pipeline after fork() starts only after what `stream` holds now (e.g. the producer of the inputs). */
+int fsr1_pipeline_fork(fsr1_pipeline* pipeline, void* stream);
+/* Work submitted to `stream` after join() starts only after everything the pipeline holds now (e.g. a consumer of the outputs). */
+int fsr1_pipeline_join(fsr1_pipeline* pipeline, void* stream);
+/* Blocks the host until the pipeline is empty. */
+int fsr1_pipeline_synchronize(fsr1_pipeline* pipeline);
+int fsr1_pipeline_streams(const fsr1_pipeline* pipeline);
+void* fsr1_pipeline_stream(const fsr1_pipeline* pipeline, int32_t i); /* the i-th hipStream_t, for callers that record events of their own */
+int fsr1_pipeline_destroy(fsr1_pipeline* pipeline);
+
+/* ------------------------------------------------------------------------------------------------
  * Diagnostics
  * ---------------------------------------------------------------------------------------------- */
 /* Thread-local message of the last failing call on this thread ("" if none). */

@@ -15,12 +15,16 @@
  *
  *   fsr1_runner [--gpus N] [--frames F] [--in WxH] [--out WxH] [--steps K] [--warmup W]
  *               [--pipeline two-pass|fused|easu|auto] [--math f|exact|h] [--sharpness STOPS] [--hdr]
- *               [--stages BITS] [--grain AMOUNT] [--ring R] [--bands] [--dry-run [--dry-fail RANK]]
+ *               [--stages BITS] [--grain AMOUNT] [--ring R] [--bands] [--streams S] [--dry-run [--dry-fail RANK]]
  *
  * --bands: strong scaling of ONE frame stream instead of weak scaling over frames — every GPU holds the whole
  * input frame and produces one band of output rows (fsr1_easu_dispatch_band on the band plus a row either side, then
  * fsr1_rcas_dispatch_band, or with --pipeline fused the single launch fsr1_easu_rcas_fused_dispatch_band); still no image
  * byte crosses a link.
+ *
+ * --streams S (default 2): every GPU sends its steps through an fsr1_pipeline of S HIP streams (include/fsr1_hip.h, "Frame
+ * pipeline"): step i on stream i mod S with that stream's own intermediary, so the tail of one step overlaps the head of the next
+ * (a kernel boundary costs ~5 us of an otherwise idle chip).  --streams 1 is the single in-order stream of rounds 1-3.
  *
  * --dry-run: the host side of an N-GPU run with no device behind it — N threads, the contiguous frame shards, the pipeline plan
  * (fsr1_upscale_plan is host arithmetic), K "steps" of 1 ms of sleep, the barrier every rank reaches before the collective, the
@@ -55,6 +59,7 @@ typedef struct {
   float grain;
   int ring; /* input / output sets to rotate over; 0 = enough to exceed 1 GiB (four times the Infinity Cache) */
   int bands; /* 1: one frame per step, split into row bands over the GPUs */
+  int streams; /* HIP streams per GPU the steps alternate over (fsr1_pipeline); 1 = one in-order stream */
   int dry;   /* 1: --dry-run (no device, no RCCL) */
   int dry_fail; /* --dry-fail RANK: that rank reports a failure before the barrier (-1: none) */
 } options_t;
@@ -80,6 +85,7 @@ typedef struct {
   hipStream_t stream;
   hipEvent_t ev0, ev1;
   void *d_in, *d_mid, *d_out, *d_noise;
+  fsr1_pipeline* pipe;
   uint64_t *d_send, *d_recv;
 } worker_t;
 
@@ -244,7 +250,7 @@ static int worker_body(worker_t* w) {
   if (nf > 0) {
     HIP_OK(w, hipMalloc(&w->d_in, in_frame * nf * ring));
     HIP_OK(w, hipMalloc(&w->d_out, out_frame * nf * ring));
-    if (needs_mid) HIP_OK(w, hipMalloc(&w->d_mid, out_frame * nf));
+    if (needs_mid && o->streams <= 1) HIP_OK(w, hipMalloc(&w->d_mid, out_frame * nf));  /* (a pipeline owns one intermediary per stream) */
     uint16_t* host = (uint16_t*)malloc(in_frame);
     if (!host) { snprintf(w->error, sizeof w->error, "out of host memory"); w->status = -1; return -1; }
     for (int s = 0; s < ring; ++s)
@@ -292,17 +298,24 @@ static int worker_body(worker_t* w) {
   }
   HIP_OK(w, hipEventCreate(&w->ev0));
   HIP_OK(w, hipEventCreate(&w->ev1));
+  if (o->streams > 1) FSR_OK(w, fsr1_pipeline_create(&w->pipe, o->streams));
   float ms = 0.f;
   if (nf > 0) {
     for (int i = -o->warmup; i < o->steps; ++i) {
-      if (i == 0) HIP_OK(w, hipEventRecord(w->ev0, stream));
+      if (i == 0) {  /* the clock starts on the control stream once everything before it has left the device */
+        if (w->pipe) FSR_OK(w, fsr1_pipeline_join(w->pipe, stream));
+        HIP_OK(w, hipEventRecord(w->ev0, stream));
+        if (w->pipe) FSR_OK(w, fsr1_pipeline_fork(w->pipe, stream));
+      }
       const size_t s = (size_t)((i + o->warmup) % ring) * (size_t)nf;
       fsr1_image in = {(char*)w->d_in + in_frame * s, o->in_w, o->in_h, FSR1_FORMAT_RGBA16F, nf, 0, 0};
       fsr1_image mid = {w->d_mid, o->out_w, o->out_h, FSR1_FORMAT_RGBA16F, nf, 0, 0};
       fsr1_image out = {(char*)w->d_out + out_frame * s, o->out_w, o->out_h, FSR1_FORMAT_RGBA16F, nf, 0, 0};
       stages.frame = (uint32_t)(i < 0 ? 0 : i); /* the grain / dither pattern changes every frame (ffx_fsr1.h:1006) */
-      FSR_OK(w, fsr1_upscale_ex(&in, w->d_mid ? &mid : NULL, &out, &p, &stages, stream));
+      if (w->pipe) FSR_OK(w, fsr1_pipeline_upscale(w->pipe, &in, &out, &p, &stages));  /* step i on stream i mod S, that stream's own intermediary */
+      else FSR_OK(w, fsr1_upscale_ex(&in, w->d_mid ? &mid : NULL, &out, &p, &stages, stream));
     }
+    if (w->pipe) FSR_OK(w, fsr1_pipeline_join(w->pipe, stream));  /* ... and stops when the last step of every stream has */
     HIP_OK(w, hipEventRecord(w->ev1, stream));
     HIP_OK(w, hipEventSynchronize(w->ev1));
     HIP_OK(w, hipEventElapsedTime(&ms, w->ev0, w->ev1));
@@ -367,6 +380,7 @@ static void* worker(void* arg) {
   if (!atomic_load(&g_abort)) (void)worker_collective(w);
   (void)hipFree(w->d_send); (void)hipFree(w->d_recv);
   (void)hipFree(w->d_in); (void)hipFree(w->d_mid); (void)hipFree(w->d_out); (void)hipFree(w->d_noise);
+  if (w->pipe) (void)fsr1_pipeline_destroy(w->pipe);
   if (w->ev0) (void)hipEventDestroy(w->ev0);
   if (w->ev1) (void)hipEventDestroy(w->ev1);
   if (w->stream) (void)hipStreamDestroy(w->stream);
@@ -381,12 +395,13 @@ static void usage(void) {
        "                   [--stages BITS] [--grain AMOUNT]   (colour stages: 1 SRTM, 2 grain, 4 SRTM inverse, 8/16 TEPD 8/10-bit)\n"
        "                   [--ring R]   (input / output sets to rotate over; default: more than 1 GiB, 4 x the Infinity Cache)\n"
        "                   [--bands]    (one frame stream split into row bands over the GPUs instead of frames per GPU)\n"
+       "                   [--streams S] (HIP streams per GPU the steps alternate over, default 2; 1 = one in-order stream)\n"
        "                   [--dry-run [--dry-fail RANK]]   (the N-thread host side without devices or RCCL: shards, plan, barrier, abort path, JSON)\n"
        "defaults: 1 GPU, 1 frame per GPU, 1920x1080 -> 3840x2160, 100 steps, 10 warmup, two-pass, f, 0.25 stops");
 }
 
 int main(int argc, char** argv) {
-  options_t o = {1, 0, 1920, 1080, 3840, 2160, 100, 10, 0, 0, 0u, 0.25f, 0u, 0.25f, 0, 0, 0, -1};
+  options_t o = {1, 0, 1920, 1080, 3840, 2160, 100, 10, 0, 0, 0u, 0.25f, 0u, 0.25f, 0, 0, 2, 0, -1};
   for (int i = 1; i < argc; ++i) {
     const char* a = argv[i];
     const char* v = i + 1 < argc ? argv[i + 1] : NULL;
@@ -404,6 +419,7 @@ int main(int argc, char** argv) {
     else if (!strcmp(a, "--stages")) { o.stages = (uint32_t)strtoul(v, NULL, 0); ++i; }
     else if (!strcmp(a, "--grain")) { o.grain = (float)atof(v); ++i; }
     else if (!strcmp(a, "--ring")) { o.ring = atoi(v); ++i; }
+    else if (!strcmp(a, "--streams")) { o.streams = atoi(v); ++i; }
     else if (!strcmp(a, "--in")) { if (!parse_size(v, &o.in_w, &o.in_h)) { fprintf(stderr, "bad --in %s\n", v); return 2; } ++i; }
     else if (!strcmp(a, "--out")) { if (!parse_size(v, &o.out_w, &o.out_h)) { fprintf(stderr, "bad --out %s\n", v); return 2; } ++i; }
     else if (!strcmp(a, "--pipeline")) {
@@ -418,7 +434,8 @@ int main(int argc, char** argv) {
       ++i;
     } else { fprintf(stderr, "unknown option %s\n", a); usage(); return 2; }
   }
-  if (o.gpus < 1 || o.steps < 1 || o.warmup < 0) { usage(); return 2; }
+  if (o.gpus < 1 || o.steps < 1 || o.warmup < 0 || o.streams < 1 || o.streams > 8) { usage(); return 2; }
+  if (o.bands) o.streams = 1; /* the band path issues its own dispatches on one stream */
   if (o.frames <= 0) o.frames = o.gpus; /* one frame per GPU */
   if (o.dry && o.bands) { fprintf(stderr, "--dry-run exercises the frames-per-GPU path\n"); return 2; }
   const int visible = o.dry ? o.gpus : fsr1_device_count();  /* --dry-run: a pretended device count */
@@ -470,12 +487,12 @@ int main(int argc, char** argv) {
     printf("{\"metric\": \"upscaled megapixels/sec\", \"value\": %.1f, \"unit\": \"Mpix/s\", \"n_gpus\": %d, \"frames\": %llu, "
            "\"steps\": %d, \"warmup\": %d, \"ms_per_step\": %.5f, \"seconds\": %.6f, \"higher_is_better\": true, \"scaling\": \"%s\", "
            "\"in\": \"%dx%d\", \"out\": \"%dx%d\", \"pipeline\": \"%s\", \"pipeline_run\": \"%s\", \"math\": \"%s\", \"color_stages\": %u, "
-           "\"algorithmic_GBps\": %.1f, \"hbm_peak_frac\": %.4f, \"rccl_ranks\": %d, \"world_size_seen\": %d, \"ring\": %d, \"intermediary\": \"%s\", \"bands\": %d, \"dry_run\": %s, \"per_gpu_ms\": [",
+           "\"algorithmic_GBps\": %.1f, \"hbm_peak_frac\": %.4f, \"rccl_ranks\": %d, \"world_size_seen\": %d, \"ring\": %d, \"intermediary\": \"%s\", \"bands\": %d, \"streams\": %d, \"dry_run\": %s, \"per_gpu_ms\": [",
            (double)pixels / sec / 1e6, o.gpus, (unsigned long long)frames, o.steps, o.warmup, sec * 1e3 / o.steps, sec, o.bands ? "strong" : "weak",
            o.in_w, o.in_h, o.out_w, o.out_h,
            o.pipeline == 0 ? "two-pass" : (o.pipeline == 1 ? "fused" : (o.pipeline == 2 ? "easu" : "auto")),
            ran == 0 ? "two-pass" : (ran == 1 ? "fused" : "easu"), o.math == FSR1_FLAG_MATH_EXACT ? "exact" : (o.math ? "h" : "f"), o.stages, bytes / sec / 1e9,
-           bytes / sec / 1e9 / (8000.0 * o.gpus), o.dry ? 0 : o.gpus, o.dry ? o.gpus : ws[0].comm_ranks, ws[0].ring, ran == 0 ? "reused" : "none", o.bands,
+           bytes / sec / 1e9 / (8000.0 * o.gpus), o.dry ? 0 : o.gpus, o.dry ? o.gpus : ws[0].comm_ranks, ws[0].ring, ran == 0 ? (o.streams > 1 ? "one per stream" : "reused") : "none", o.bands, o.streams,
            o.dry ? "true" : "false");
     for (int i = 0; i < o.gpus; ++i) printf("%s%.3f", i ? ", " : "", (double)gathered[3 * i + 2] * 1e-6);
     printf("], \"per_rank_seconds\": [");

@@ -52,3 +52,17 @@ def test_only_the_fused_figure_suspect():
 def test_median():
     assert bench.median([3, 1, 2]) == 2 and bench.median([4, 1, 2, 3]) == 2.5 and bench.median([7]) == 7
     assert bench.reduce_regions([0.5, 0.25], None) == [0.5, 0.25]  # identity without a process group
+
+
+def test_pipelined_line_is_judged_against_the_one_stream_step():
+    """--streams 2: steps overlap, so the headline step (60.2 us) is shorter than the kernels it contains (40.1 + 24.7 us); the check
+    compares the kernels with the in-order step the line carries beside it (config.one_stream) — consistent — and still flags a broken
+    stopwatch there."""
+    line = _line(40.12, 24.68, 0.0602, 59.87, 0.0564)
+    line["config"] = {"streams": 2, "one_stream": {"ms_per_step": 0.0656, "value": 126400.0}}
+    line["also_measured"]["fused"]["one_stream"] = {"ms_per_step": 0.0605, "value": 137100.0}
+    assert bench.check_stopwatch(line) == [] and line["stopwatch_suspect"] is False
+    bad = _line(54.95, 30.2, 0.0602, 77.82, 0.0564)
+    bad["config"] = {"streams": 2, "one_stream": {"ms_per_step": 0.0656}}
+    bad["also_measured"]["fused"]["one_stream"] = {"ms_per_step": 0.0605}
+    assert len(bench.check_stopwatch(bad)) == 2 and bad["stopwatch_suspect"] is True
