@@ -27,6 +27,7 @@ FLAG_MATH_PACKED_FP16 = 1 << 5
 FLAG_NO_FAST_PATHS = 1 << 8
 FLAG_OUTPUT_STREAMING = 1 << 9
 FLAG_OUTPUT_CACHED = 1 << 10
+FLAG_FRAMES_OVERLAP = 1 << 11
 
 # colour stages (ffx_fsr1.h:986-1199), fixed order SRTM -> LFGA -> SRTM_INV -> TEPD
 COLOR_SRTM = 1 << 0

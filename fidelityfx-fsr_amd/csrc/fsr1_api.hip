@@ -23,7 +23,7 @@ hipError_t fused_s2_launch(const FusedArgs& a, int fmt, bool exact, bool tall, h
 size_t fused_s2_lds_bytes(int fmt, int waves);
 bool fused_s2_tall_tiles(int width, int height, int frames, int steps, int cus, int fmt);
 void fused_s2_geometry(int width, int height, int steps, int* tiles_x, int* tiles_y, int step_rows);
-int fused_s2_run_steps(int width, int height, int frames, int cus, int wgs_per_cu);
+int fused_s2_run_steps(int width, int height, int frames, int cus, int wgs_per_cu, bool overlapped);
 hipError_t fused_s2_h_launch(const FusedArgs& a, hipStream_t stream);
 size_t fused_s2_h_lds_bytes();
 void fused_s2_force_steps(int steps);
@@ -181,7 +181,7 @@ static int check_grid(const char* who, int tiles_x, int tiles_y, int frames) {
 
 static const uint32_t kKnownFlags = FSR1_FLAG_HDR_SQUARE | FSR1_FLAG_RCAS_DENOISE | FSR1_FLAG_RCAS_PASSTHROUGH_ALPHA |
                                     FSR1_FLAG_MATH_EXACT | FSR1_FLAG_MATH_PACKED_FP16 | FSR1_FLAG_NO_FAST_PATHS |
-                                    FSR1_FLAG_OUTPUT_STREAMING | FSR1_FLAG_OUTPUT_CACHED;
+                                    FSR1_FLAG_OUTPUT_STREAMING | FSR1_FLAG_OUTPUT_CACHED | FSR1_FLAG_FRAMES_OVERLAP;
 
 static int check_flags(uint32_t flags) {
   if (flags & ~kKnownFlags) return fail(FSR1_ERR_INVALID_ARGUMENT, "unknown flag bits 0x%x", flags & ~kKnownFlags);
@@ -510,7 +510,7 @@ static int fused_dispatch_impl(const fsr1_image* in, const fsr1_image* out, cons
   const bool s2 = easu_con[0] == 0x3f000000u && easu_con[1] == 0x3f000000u && easu_con[2] == 0xbe800000u && easu_con[3] == 0xbe800000u &&
                   !(flags & FSR1_FLAG_NO_FAST_PATHS) && !a.color.stages && !(origin_y & 1) &&
                   (packed ? origin_y == 0 && !rows_above && !rows_below : fused_s2_lds_bytes(in->format, 4) <= 160 * 1024);
-  a.run_steps = s2 ? fused_s2_run_steps(out->width, out->height, out->frames, device_cus(), packed ? 5 : 7) : 0;
+  a.run_steps = s2 ? fused_s2_run_steps(out->width, out->height, out->frames, device_cus(), packed ? 5 : 7, (flags & FSR1_FLAG_FRAMES_OVERLAP) != 0) : 0;
   const bool tall = s2 && !packed && fused_s2_tall_tiles(out->width, out->height, out->frames, a.run_steps, device_cus(), in->format);
   if (s2) fused_s2_geometry(out->width, out->height, a.run_steps, &a.tiles_x, &a.tiles_y, tall ? 2 * kFs2Step : kFs2Step);
   if ((rc = check_grid("fused", a.tiles_x, a.tiles_y, a.frames))) return rc;
@@ -590,8 +590,10 @@ static int upscale_decide(const char* who, const fsr1_image* in, bool have_inter
   plan->math = p->flags & (FSR1_FLAG_MATH_EXACT | FSR1_FLAG_MATH_PACKED_FP16 | FSR1_FLAG_NO_FAST_PATHS);
   const uint32_t rcas_opts = p->flags & (FSR1_FLAG_RCAS_DENOISE | FSR1_FLAG_RCAS_PASSTHROUGH_ALPHA);
   plan->out_policy = p->flags & (FSR1_FLAG_OUTPUT_STREAMING | FSR1_FLAG_OUTPUT_CACHED);  // of the pass that writes `out`
-  if (p->flags & ~(plan->math | rcas_opts | plan->out_policy))
-    return fail(FSR1_ERR_INVALID_ARGUMENT, "%s: params.flags may only hold MATH_*, RCAS_* and OUTPUT_* bits", who);
+  const uint32_t overlap = p->flags & FSR1_FLAG_FRAMES_OVERLAP;  // a scheduling hint: travels with the math bits to every pass
+  if (p->flags & ~(plan->math | rcas_opts | plan->out_policy | overlap))
+    return fail(FSR1_ERR_INVALID_ARGUMENT, "%s: params.flags may only hold MATH_*, RCAS_*, OUTPUT_* and FRAMES_OVERLAP bits", who);
+  plan->math |= overlap;
   if ((plan->math & FSR1_FLAG_MATH_PACKED_FP16) && (in->format != FSR1_FORMAT_RGBA16F || out->format != FSR1_FORMAT_RGBA16F || have_stages))
     return fail(FSR1_ERR_UNSUPPORTED, "%s: packed-fp16 math needs RGBA16F images and runs without colour stages", who);
   // :106 — viewport == input resource size == (renderWidth, renderHeight); output = display size
@@ -746,6 +748,7 @@ int fsr1_pipeline_upscale(fsr1_pipeline* p, const fsr1_image* in, const fsr1_ima
   }
   // (the plan is re-derived by fsr1_upscale_ex from the same arguments: `auto` with an intermediary on offer decides as it did above)
   fsr1_params prm = *params;
+  if (p->n > 1) prm.flags |= FSR1_FLAG_FRAMES_OVERLAP;         // the frames of this pipeline run beside each other
   if (plan.pipeline == 1) prm.fused = 1;                         // what was decided, whatever `auto` would say without an intermediary
   else if (plan.pipeline == 0) prm.fused = 0;
   if (int rc = fsr1_upscale_ex(in, mid_p, out, &prm, stages, p->streams[slot])) return rc;

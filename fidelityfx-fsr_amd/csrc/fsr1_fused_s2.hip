@@ -41,12 +41,18 @@ constexpr int kFs2MaxSteps = 8;
 // the same image (tests/test_gpu_parity.py::test_fused_exact_2x_run_steps); tuning runs set it through the same call.
 static std::atomic<int> g_fs2_forced_steps{0};
 void fused_s2_force_steps(int steps) { g_fs2_forced_steps.store(steps < 0 ? 0 : (steps > 64 ? 64 : steps), std::memory_order_relaxed); }
-int fused_s2_run_steps(int width, int height, int frames, int cus, int wgs_per_cu) {
+int fused_s2_run_steps(int width, int height, int frames, int cus, int wgs_per_cu, bool overlapped) {
   if (const int forced = g_fs2_forced_steps.load(std::memory_order_relaxed); forced > 0) return forced;
   const long long tiles1 = (long long)((width + kFs2OutW - 1) / kFs2OutW) * ((height + kFs2Step - 3) / (kFs2Step - 2)) * frames;
   // (cus: the device's compute units — 256 on MI355X, where the rule was measured; wgs_per_cu: what the kernel's LDS admits, 7 for
   //  the F kernel, 5 for the packed-fp16 one)
-  const long long s = tiles1 / (5ll * (cus > 0 ? cus : 256) * (wgs_per_cu > 0 ? wgs_per_cu : 7));
+  const long long slots = (long long)(cus > 0 ? cus : 256) * (wgs_per_cu > 0 ? wgs_per_cu : 7);
+  // overlapped (FSR1_FLAG_FRAMES_OVERLAP: other frames run beside this launch on other streams, fsr1_pipeline): the tail of a launch
+  // is filled by its neighbour's head, so the launch no longer has to keep every CU supplied to its own end and runs as long as
+  // the apron saving asks for — one 4K frame walks 4 steps (profiles/ab_r04/r4c4_two_stream_walk.log, two streams, us per frame:
+  // one-step 58.2-58.6, tall tile 56.6, S = 2 / 3 / 4 / 6 / 8: 55.8 / 54.8-55.1 / 53.9-54.2 / 54.2-54.3 / 55.9; 1440p output:
+  // 26.3-26.6 one-step, 25.2-25.3 / 25.3-25.4 / 25.7 / 28.5 at 2 / 3 / 4 / 6): about 1.25 residencies of runs.
+  const long long s = overlapped ? (4 * tiles1 + 5 * slots / 2) / (5 * slots) : tiles1 / (5 * slots);
   return (int)(s < 1 ? 1 : s > kFs2MaxSteps ? kFs2MaxSteps : s);
 }
 

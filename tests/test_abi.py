@@ -43,7 +43,7 @@ def test_argument_validation(fsr):
     assert lib.fsr1_easu_dispatch(ctypes.byref(bad), ctypes.byref(bad), p, 0, None) == -2  # unsupported format
     ok = fsr.fsr1_image(0x1000, 16, 16, 0, 1, 0, 0)
     ok2 = fsr.fsr1_image(0x100000, 32, 32, 0, 1, 0, 0)
-    assert lib.fsr1_easu_dispatch(ctypes.byref(ok), ctypes.byref(ok2), p, 1 << 11, None) == -1  # unknown flag
+    assert lib.fsr1_easu_dispatch(ctypes.byref(ok), ctypes.byref(ok2), p, 1 << 12, None) == -1  # unknown flag (bit 11 is FSR1_FLAG_FRAMES_OVERLAP)
     assert b"unknown flag" in lib.fsr1_last_error()
     assert lib.fsr1_easu_dispatch(ctypes.byref(ok), ctypes.byref(ok2), p, (1 << 9) | (1 << 10), None) == -1  # store policies are exclusive
     assert b"OUTPUT" in lib.fsr1_last_error()

@@ -16,7 +16,7 @@ from conftest import ROOT
 def geometry(tmp_path_factory):
     text = open(os.path.join(ROOT, "fidelityfx-fsr_amd", "csrc", "fsr1_fused_s2.hip")).read()
     consts = re.search(r"constexpr int kFs2OutW = .*?;\nconstexpr int kFs2QH = .*?;", open(os.path.join(ROOT, "fidelityfx-fsr_amd", "csrc", "fsr1_device.h")).read(), flags=re.S)
-    steps = re.search(r"constexpr int kFs2MaxSteps = .*?\nint fused_s2_run_steps\(int width, int height, int frames, int cus, int wgs_per_cu\) \{.*?\n\}\n", text, flags=re.S)
+    steps = re.search(r"constexpr int kFs2MaxSteps = .*?\nint fused_s2_run_steps\(int width, int height, int frames, int cus, int wgs_per_cu, bool overlapped\) \{.*?\n\}\n", text, flags=re.S)
     geo = re.search(r"static std::atomic<int> g_fs2_forced_tall.*?\nbool fused_s2_tall_tiles\(int width, int height, int frames, int steps, int cus, int fmt\) \{.*?\n\}\n\nvoid fused_s2_geometry\(int width, int height, int steps, int\* tiles_x, int\* tiles_y, int step_rows\) \{.*?\n\}\n", text, flags=re.S)
     assert consts and steps and geo, "host geometry functions not found in fsr1_fused_s2.hip"
     tmp = tmp_path_factory.mktemp("walk")
@@ -24,14 +24,14 @@ def geometry(tmp_path_factory):
     src.write_text("#include <atomic>\n#include <cstdio>\n#include <cstdlib>\nenum { FSR1_FORMAT_RGBA16F = 0, FSR1_FORMAT_RGBA32F = 1 };\n" + consts.group(0) + "\n" + steps.group(0) + geo.group(0) +
                    "int main(int argc, char** argv) { int w = atoi(argv[1]), h = atoi(argv[2]), f = atoi(argv[3]), cus = atoi(argv[4]);\n"
                    "  fused_s2_force_steps(atoi(argv[5]));  // the test hook's path (fsr1_debug_fused_run_steps); 0 = the rule\n"
-                   "  int s = fused_s2_run_steps(w, h, f, cus, argc > 6 ? atoi(argv[6]) : 7), tx, ty; fused_s2_geometry(w, h, s, &tx, &ty, kFs2Step);\n"
+                   "  int s = fused_s2_run_steps(w, h, f, cus, argc > 6 ? atoi(argv[6]) : 7, argc > 7 && atoi(argv[7])), tx, ty; fused_s2_geometry(w, h, s, &tx, &ty, kFs2Step);\n"
                    "  int tall = fused_s2_tall_tiles(w, h, f, s, cus, 0), ttx = 0, tty = 0; if (tall) fused_s2_geometry(w, h, s, &ttx, &tty, 2 * kFs2Step);\n"
                    "  std::printf(\"%d %d %d %d %d %d %d\\n\", s, tx, ty, kFs2Step, tall, ttx, tty); return 0; }\n")
     exe = tmp / "walk"
     subprocess.check_call(["g++", "-std=c++17", "-O1", "-o", str(exe), str(src)])
 
-    def run(w, h, frames, forced=0, cus=256, wgs=7):
-        return [int(x) for x in subprocess.check_output([str(exe), str(w), str(h), str(frames), str(cus), str(forced), str(wgs)], text=True).split()]
+    def run(w, h, frames, forced=0, cus=256, wgs=7, overlapped=0):
+        return [int(x) for x in subprocess.check_output([str(exe), str(w), str(h), str(frames), str(cus), str(forced), str(wgs), str(overlapped)], text=True).split()]
     return run
 
 
@@ -52,6 +52,19 @@ def test_steps_scale_with_the_compute_units(geometry):
     # the packed-fp16 twin holds five workgroups per CU instead of seven: the same launches are more residencies long
     assert geometry(3840, 2160, 1, wgs=5)[0] == 1 and geometry(3840, 2160, 4, wgs=5)[0] == 6 and geometry(7680, 4320, 16, wgs=5)[0] == 8
     assert geometry(3840, 2160, 1, forced=200)[0] == 64 and geometry(3840, 2160, 1, forced=-3)[0] == 1  # the hook clamps to 0 .. 64
+
+
+def test_overlapped_launches_walk_longer_runs(geometry):
+    """FSR1_FLAG_FRAMES_OVERLAP (frames pipelined over several streams, fsr1_pipeline): the tail of a launch is filled by the next
+    frame's head, so a single 4K frame walks 4 steps, a 1440p output 2, a 1080p output stays on one-step tiles, an 8K frame 8 — the
+    measured optima of profiles/ab_r04/r4c4_two_stream_walk.log; and the runs still cover the image."""
+    assert geometry(3840, 2160, 1, overlapped=1)[0] == 4 and geometry(2560, 1440, 1, overlapped=1)[0] == 2
+    assert geometry(1920, 1080, 1, overlapped=1)[0] == 1 and geometry(7680, 4320, 1, overlapped=1)[0] == 8
+    assert geometry(3840, 2160, 1, overlapped=1)[4] == 0  # a walking launch is never tall
+    for (w, h) in ((3840, 2160), (2560, 1440), (194, 320)):
+        s, tx, ty = geometry(w, h, 1, overlapped=1)[:3]
+        run = 16 * s - 2
+        assert tx * 62 >= w and (ty - 1) * run < h <= ty * run
 
 
 def test_tall_tiles_for_one_step_launches_that_fill_the_chip(geometry):

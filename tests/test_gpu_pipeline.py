@@ -52,6 +52,28 @@ def test_pipelined_frames_equal_frames_upscaled_alone(fsr, streams, mode):
     pipe.close()
 
 
+def test_pipelined_4k_frames_walk_and_equal_the_two_dispatches(fsr):
+    """On a pipeline of two streams the exact-2x fused launch of a 4K frame walks its columns in 4-step runs (FSR1_FLAG_FRAMES_OVERLAP),
+    alone it runs tall one-step tiles: both are the two dispatches' image, and so are the pipelined two dispatches themselves."""
+    iw, ih, ow, oh = 1920, 1080, 3840, 2160
+    srcs = [dev(frames.synthetic_frame(iw, ih, k=90 + k, dtype=np.float16)) for k in range(4)]
+    want = [alone(fsr, s, ow, oh, False, 0) for s in srcs]
+    pipe = fsr.Pipeline(2)
+    for fused in (1, 0, 2):
+        outs = [torch.zeros(oh, ow, 4, dtype=torch.float16, device="cuda") for _ in srcs]
+        torch.cuda.synchronize()
+        for s, o in zip(srcs, outs):
+            pipe.upscale(s, o, fused=fused)
+        pipe.synchronize()
+        for k in range(4):
+            assert torch.equal(outs[k].view(torch.int16), want[k].view(torch.int16)), (fused, k)
+    pipe.close()
+    one = torch.zeros(oh, ow, 4, dtype=torch.float16, device="cuda")
+    fsr.easu_rcas_fused(srcs[0], one, flags=fsr.FLAG_FRAMES_OVERLAP)  # the hint given by hand
+    torch.cuda.synchronize()
+    assert torch.equal(one.view(torch.int16), want[0].view(torch.int16))
+
+
 def test_pipeline_fork_and_join_order_against_the_callers_stream(fsr):
     """Inputs produced on the caller's stream right before fork(), outputs consumed on it right after join(): no host synchronisation."""
     iw, ih, ow, oh = 480, 270, 960, 540
