@@ -15,7 +15,7 @@ namespace fsr1 {
 hipError_t easu_launch(const EasuArgs& a, int fmt, bool exact, bool s2, hipStream_t stream);
 size_t easu_lds_bytes(int fmt, int fp_w, int fp_h);
 hipError_t rcas_launch(const RcasArgs& a, int fmt, bool exact, hipStream_t stream);
-void rcas_geometry(int width, int height, int frames, int* tiles_x, int* tiles_y, int* rows);
+void rcas_geometry(int width, int height, int frames, bool overlapped, int* tiles_x, int* tiles_y, int* rows);
 hipError_t fused_launch(const FusedArgs& a, int fmt, bool exact, hipStream_t stream);
 size_t fused_lds_bytes(int fmt, int fp_w, int fp_h);
 hipError_t fused_h_launch(const FusedArgs& a, hipStream_t stream);
@@ -421,7 +421,7 @@ static int rcas_dispatch_impl(const fsr1_image* in, const fsr1_image* out, const
   }
   if ((rows_above || rows_below) && in->frames != 1) return fail(FSR1_ERR_UNSUPPORTED, "rcas band: one frame per dispatch");
   memcpy(a.con, con, sizeof a.con);
-  rcas_geometry(out->width, out->height, out->frames, &a.tiles_x, &a.tiles_y, &a.rows);
+  rcas_geometry(out->width, out->height, out->frames, (flags & FSR1_FLAG_FRAMES_OVERLAP) != 0, &a.tiles_x, &a.tiles_y, &a.rows);
   a.frames = out->frames;
   if ((rc = check_grid("rcas", a.tiles_x, a.tiles_y, a.frames))) return rc;
   a.flags = resolve_output_policy(flags, true);

@@ -29,11 +29,13 @@ constexpr int kRcasShallowRing = 2;  // rows in flight per lane when the launch 
 // workgroups divide evenly over the CUs and however deep the per-lane prefetch ring is: what counts is the number
 // of independent row streams in flight, and the apron rows that shorter strips re-read are cheap next to it.
 // 16 rows (two apron rows per 16 = 12.5 % extra reads, mostly L2/MALL hits) unless that leaves fewer than four
-// waves per SIMD, then 8.
-void rcas_geometry(int width, int height, int frames, int* tiles_x, int* tiles_y, int* rows) {
+// waves per SIMD, then 8 — unless the launch runs beside other frames' launches (FSR1_FLAG_FRAMES_OVERLAP, fsr1_pipeline): then the
+// neighbour's waves fill the chip and the bytes count again: 16 rows (round 4, two streams, us per frame: 1080p -> 4K 60.3-60.4 ->
+// 59.4-59.6, 1440p -> 4K 70.9 -> 69.7-70.0; on one stream the same strips LOSE 5 %: profiles/ab_r04/r4c5_two_stream_rcas_rows.log).
+void rcas_geometry(int width, int height, int frames, bool overlapped, int* tiles_x, int* tiles_y, int* rows) {
   const int tx = (width + kRcasCols - 1) / kRcasCols;
   int r = 16;
-  if ((long long)tx * ((height + r - 1) / r) * frames * kRcasWaves < 4LL * 4 * 256) r = 8;
+  if (!overlapped && (long long)tx * ((height + r - 1) / r) * frames * kRcasWaves < 4LL * 4 * 256) r = 8;
   *rows = r;
   *tiles_x = tx;
   *tiles_y = (height + r - 1) / r;
