@@ -11,6 +11,8 @@ print("| profile (`profiles/%s_*`) | Mpix/s | µs per step | EASU µs (frac of 8
 print("|---|---|---|---|---|---|")
 for f in sorted(glob.glob(os.path.join(ROOT, "profiles", tag + "_*.line"))):
     name = os.path.basename(f)[len(tag) + 1:-5]
+    if not os.path.exists(f[:-5] + ".json"):
+        continue  # (a trace without a PMC summary, e.g. the r04 *_two_streams kernel-trace of the pipelined regime)
     line = json.loads(open(f).read())
     prof = json.load(open(f[:-5] + ".json"))
     h = line["config"].get("workload", "").find("math=h") >= 0
