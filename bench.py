@@ -332,8 +332,8 @@ def main():
         raise SystemExit("--regions must be >= 1")
     if not 1 <= args.streams <= 8:
         raise SystemExit("--streams must be 1 .. 8")
-    if args.pipeline == "color" or args.graph or args.rotate_intermediary:
-        args.streams = 1  # (the colour pass is not an upscale; a hipGraph / a rotated intermediary are single-stream experiments)
+    if args.pipeline == "color" or args.rotate_intermediary:
+        args.streams = 1  # (the colour pass is not an upscale; a rotated intermediary is a single-stream experiment)
     if os.environ.get("WORLD_SIZE", "1") == "1" and args.gpus > 1 and os.environ.get("FSR1_BENCH_SELF_LAUNCHED") != "1":
         # started like `--gpus 1` is: one bare python process.  Start the ranks ourselves, exactly as the other launch style does.
         raise SystemExit(self_launch(sys.argv[1:], args.gpus))
@@ -500,9 +500,15 @@ def main():
         # K steps = K / graph replays of a hipGraph holding `graph` consecutive steps (ring slots 0 .. graph-1, ...)
         args.steps = max(args.graph, args.steps // args.graph * args.graph)
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            for i in range(args.graph):
-                step(i)
+        cap = torch.cuda.Stream()
+        with torch.cuda.stream(cap):
+            with torch.cuda.graph(g, stream=cap):
+                if pipe is not None:
+                    pipe.fork(cap)  # the pipeline's streams join the capture: the graph holds `streams` parallel chains of steps
+                for i in range(args.graph):
+                    step(i)
+                if pipe is not None:
+                    pipe.join(cap)
         g.replay()
         regions, own_regions = timed(lambda i: g.replay(), args.steps // args.graph)
     else:

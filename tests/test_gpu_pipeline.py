@@ -74,6 +74,74 @@ def test_pipelined_4k_frames_walk_and_equal_the_two_dispatches(fsr):
     assert torch.equal(one.view(torch.int16), want[0].view(torch.int16))
 
 
+def test_pipelined_frames_with_colour_stages_unorm_and_batches(fsr):
+    """Colour stages (prologue on EASU's loads, epilogue on the pass that writes the output), RGBA8 storage and batched frames go
+    through the pipeline like through fsr1_upscale_ex: every submission equals the same submission made alone on one stream."""
+    rng = np.random.default_rng(7)
+    noise = dev((rng.random((4, 32, 32, 4)) - np.array([0.5, 0.5, 0.5, 0.0])).astype(np.float16))
+    stages = fsr.ColorStages(1 | 2 | 4, grain_amount=0.3, frame=5, noise=noise)
+    iw, ih, ow, oh = 200, 120, 300, 180
+    n = 3
+    src16 = dev(np.stack([frames.synthetic_frame(iw, ih, k=30 + f, dtype=np.float16) for f in range(n)]))
+    src8 = (src16.float().clamp(0, 1) * 255 + 0.5).to(torch.uint8)
+    lib = fsr.load()
+
+    def alone_ex(src, fused, st):
+        out = torch.zeros(n, oh, ow, 4, dtype=src.dtype, device="cuda")
+        f = fsr.FSR_Filter()
+        f.OnCreate(slowFallback=True, fused=bool(fused))
+        f.OnCreateWindowSizeDependentResources(src, out, ow, oh)
+        f.Upscale(ow, oh, fsr.State(iw, ih, bUseRcas=True, rcasAttenuation=0.25), stages=st)
+        torch.cuda.synchronize()
+        return out
+
+    for streams in (2, 3):
+        pipe = fsr.Pipeline(streams)
+        for src, st in ((src16, stages), (src16, None), (src8, None)):
+            for fused in (0, 1):
+                want = alone_ex(src, fused, st)
+                outs = [torch.zeros(n, oh, ow, 4, dtype=src.dtype, device="cuda") for _ in range(4)]
+                torch.cuda.synchronize()
+                for o in outs:
+                    pipe.upscale(src, o, sharpness=0.25, fused=fused, stages=st)
+                pipe.synchronize()
+                for k, o in enumerate(outs):
+                    assert torch.equal(o, want), (streams, str(src.dtype), fused, st is not None, k)
+        pipe.close()
+    assert lib.fsr1_pipeline_streams(None) == 0 and lib.fsr1_pipeline_stream(None, 0) is None
+
+
+def test_pipeline_is_graph_capturable(fsr):
+    """fork / upscale / join record into a stream capture (the pipeline's streams join it through the fork event), so a group of
+    frames replays as one hipGraph with `streams` parallel chains — the launch-bound small-frame case (bench.py --graph)."""
+    iw, ih, ow, oh = 240, 135, 480, 270
+    srcs = [dev(frames.synthetic_frame(iw, ih, k=40 + k, dtype=np.float16)) for k in range(6)]
+    want = [alone(fsr, s, ow, oh, False, 0) for s in srcs]
+    outs = [torch.zeros(oh, ow, 4, dtype=torch.float16, device="cuda") for _ in srcs]
+    pipe = fsr.Pipeline(2)
+    for s, o in zip(srcs, outs):  # first use allocates the per-stream intermediaries (not allowed inside a capture)
+        pipe.upscale(s, o, fused=0)
+    pipe.synchronize()
+    for o in outs:
+        o.zero_()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    cap = torch.cuda.Stream()
+    with torch.cuda.stream(cap):
+        with torch.cuda.graph(g, stream=cap):
+            pipe.fork(cap)
+            for s, o in zip(srcs, outs):
+                pipe.upscale(s, o, fused=0)
+            pipe.join(cap)
+    for _ in range(3):
+        g.replay()
+    torch.cuda.synchronize()
+    for k in range(6):
+        assert torch.equal(outs[k].view(torch.int16), want[k].view(torch.int16)), k
+    del g
+    pipe.close()
+
+
 def test_pipeline_fork_and_join_order_against_the_callers_stream(fsr):
     """Inputs produced on the caller's stream right before fork(), outputs consumed on it right after join(): no host synchronisation."""
     iw, ih, ow, oh = 480, 270, 960, 540
