@@ -725,6 +725,8 @@ int fsr1_pipeline_create(fsr1_pipeline** out, int32_t streams) {
 int fsr1_pipeline_upscale(fsr1_pipeline* p, const fsr1_image* in, const fsr1_image* out, const fsr1_params* params,
                           const fsr1_color_stages* stages) {
   if (!p || p->n < 1) return fail(FSR1_ERR_INVALID_ARGUMENT, "pipeline_upscale: null pipeline");
+  if (int dev = -1; hipGetDevice(&dev) != hipSuccess || dev != p->device)  // its streams and intermediaries live on the device it was created on
+    return fail(FSR1_ERR_INVALID_ARGUMENT, "pipeline_upscale: the pipeline belongs to device %d, the calling thread's current device is %d", p->device, dev);
   if (stages && !stages->stages) stages = nullptr;
   UpscalePlan plan;
   if (int rc = upscale_decide("pipeline_upscale", in, true, out, params, stages != nullptr, &plan)) return rc;
