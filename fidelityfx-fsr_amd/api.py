@@ -401,8 +401,9 @@ class Pipeline:
 
 
 def selftest():
-    """Number of binary16 operands (of 65536) for which the packed-fp16 kernels' reciprocal is not the
-    correctly rounded 1/x; 0 on a conforming device."""
+    """fsr1_selftest: the number of operands for which (a) the packed-fp16 kernels' reciprocal (all 65536 binary16 operands) or
+    (b) the EXACT variants' binary32 reciprocal rcp_ieee (all 2^32 binary32 operands) is not the correctly rounded 1/x; 0 on a
+    conforming device."""
     n = ctypes.c_uint32(0)
     _lib.check(_lib.load().fsr1_selftest(ctypes.byref(n)))
     return int(n.value)

@@ -668,3 +668,14 @@ def test_fused_exact_2x_tall_tiles(fsr, shape):
         assert torch.equal(one8, two8)
     finally:
         lib.fsr1_debug_fused_tall_tiles(-1)
+
+
+def test_selftest_binary32_rcp_ieee_over_all_operands(fsr):
+    """fsr1_selftest() also runs the EXACT variants' 6-instruction reciprocal rcp_ieee (include/fsr1_device_base.hpp) against the IEEE
+    division 1.0f / x for ALL 2^32 binary32 operands on the device (selftest_rcp_kernel, csrc/fsr1_api.hip) — the measurement behind
+    "EXACT is bit-identical to the reference's ARcpF1" — next to the exhaustive binary16 check of the H kernels' reciprocal
+    (tests/test_gpu_parity_h.py): 0 differing operands."""
+    import time
+    t0 = time.perf_counter()
+    assert fsr.selftest() == 0
+    assert time.perf_counter() - t0 < 30.0  # 2^32 operands take about a second on an MI355X
