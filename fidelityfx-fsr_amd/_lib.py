@@ -144,11 +144,6 @@ def load():
             fn.restype = res
             fn.argtypes = args
         _lib = lib
-        forced = os.environ.get("FSR1_FUSED_S2_STEPS")  # tuning runs (tools/abtest.py `lib%FSR1_FUSED_S2_STEPS=n`): the library itself reads no environment
-        if forced:
-            lib.fsr1_debug_fused_run_steps(int(forced))
-        if os.environ.get("FSR1_FUSED_S2_TALL"):  # -1 / 0 / 1, tuning runs only
-            lib.fsr1_debug_fused_tall_tiles(int(os.environ["FSR1_FUSED_S2_TALL"]))
     return _lib
 
 

@@ -24,7 +24,13 @@ def child(args):
     import torch
     import bench
     fsr = importlib.import_module("fidelityfx-fsr_amd")
-    fsr.load()
+    lib = fsr.load()
+    # `lib%FSR1_FUSED_S2_STEPS=n` / `%FSR1_FUSED_S2_TALL=m` in --libs: the variant runs with the library's test hooks set (the library
+    # itself reads no tuning value from the environment)
+    if os.environ.get("FSR1_FUSED_S2_STEPS") and hasattr(lib, "fsr1_debug_fused_run_steps"):
+        lib.fsr1_debug_fused_run_steps(int(os.environ["FSR1_FUSED_S2_STEPS"]))
+    if os.environ.get("FSR1_FUSED_S2_TALL") and hasattr(lib, "fsr1_debug_fused_tall_tiles"):
+        lib.fsr1_debug_fused_tall_tiles(int(os.environ["FSR1_FUSED_S2_TALL"]))
     dev = torch.device("cuda", 0)
     flags = {"f": 0, "exact": fsr.FLAG_MATH_EXACT, "h": fsr.FLAG_MATH_PACKED_FP16}[args.math]
     if args.no_fast_paths:
