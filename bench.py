@@ -288,7 +288,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--regions", type=int, default=7,
                     help="timed regions of exactly --steps steps each (barrier + synchronize either side); the line reports the median region")
-    ap.add_argument("--streams", type=int, default=2,
+    ap.add_argument("--streams", type=int, default=3,
                     help="HIP streams per GPU the steps alternate over (fsr1_pipeline: step i on stream i mod S, each stream with its own "
                          "intermediary, so the tail of one step overlaps the head of the next); 1 = every step on one in-order stream, "
                          "the method of rounds 1-3, which the line also reports as config.one_stream")

@@ -88,6 +88,7 @@ SYMBOLS = {
     "fsr1_selftest": (ctypes.c_int, [_U32P]),
     "fsr1_debug_fused_run_steps": (None, [ctypes.c_int32]),
     "fsr1_debug_fused_tall_tiles": (None, [ctypes.c_int32]),
+    "fsr1_debug_easu_tall_tiles": (None, [ctypes.c_int32]),
     "fsr1_timer_create": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p)]),
     "fsr1_timer_start": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     "fsr1_timer_stop": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),

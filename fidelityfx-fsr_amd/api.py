@@ -364,7 +364,7 @@ class Pipeline:
     overlaps the head of the next (a kernel boundary costs ~5 us on MI355X).  The tensors of calls that may overlap — the last
     `streams` — must not alias; fork() / join() order the pipeline against a torch stream (default: the current one)."""
 
-    def __init__(self, streams=2):
+    def __init__(self, streams=3):
         self._h = ctypes.c_void_p()
         _lib.check(_lib.load().fsr1_pipeline_create(ctypes.byref(self._h), int(streams)))
         self.streams = int(streams)

@@ -12,7 +12,9 @@
 #include "fsr1_device.h"
 
 namespace fsr1 {
-hipError_t easu_launch(const EasuArgs& a, int fmt, bool exact, bool s2, hipStream_t stream);
+hipError_t easu_launch(const EasuArgs& a, int fmt, bool exact, bool s2, bool tall, hipStream_t stream);
+bool easu_s2_tall_tiles(int width, int height, int frames, bool overlapped, int cus);
+void easu_force_tall(int mode);
 size_t easu_lds_bytes(int fmt, int fp_w, int fp_h);
 hipError_t rcas_launch(const RcasArgs& a, int fmt, bool exact, hipStream_t stream);
 void rcas_geometry(int width, int height, int frames, bool overlapped, int* tiles_x, int* tiles_y, int* rows);
@@ -354,11 +356,15 @@ static int easu_dispatch_impl(const fsr1_image* in, const fsr1_image* out, const
   // more tile per axis when the size is a multiple of the tile, and the footprint of a tile is 64/2+3 x 16/2+3 texels.
   const bool s2 = con[0] == 0x3f000000u && con[1] == 0x3f000000u && con[2] == 0xbe800000u && con[3] == 0xbe800000u &&
                   !(flags & FSR1_FLAG_NO_FAST_PATHS) && !a.color.stages && kTileH % 16 == 0 && !((origin_x | origin_y) & 1);
+  // (64 x 32 tiles for whole-image F launches that are large or overlapped: easu_s2_tall_tiles)
+  const bool tall = s2 && !(flags & (FSR1_FLAG_MATH_PACKED_FP16 | FSR1_FLAG_MATH_EXACT)) && !origin_x && !origin_y &&
+                    easu_s2_tall_tiles(out->width, out->height, out->frames, (flags & FSR1_FLAG_FRAMES_OVERLAP) != 0, device_cus());
   if (s2) {
+    const int th = tall ? 2 * kTileH : kTileH;
     a.tiles_x = (out->width + 1 + kTileW - 1) / kTileW;
-    a.tiles_y = (out->height + 1 + kTileH - 1) / kTileH;
+    a.tiles_y = (out->height + 1 + th - 1) / th;
     a.fp_w = kTileW / 2 + 3;
-    a.fp_h = kTileH / 2 + 3;
+    a.fp_h = th / 2 + 3;
   }
   if ((rc = check_grid("easu", a.tiles_x, a.tiles_y, a.frames))) return rc;
   hipError_t e;
@@ -368,7 +374,7 @@ static int easu_dispatch_impl(const fsr1_image* in, const fsr1_image* out, const
   } else if (a.color.stages) {
     e = easu_color_launch(a, in->format, out->format, (flags & FSR1_FLAG_MATH_EXACT) != 0, static_cast<hipStream_t>(stream));
   } else {
-    e = easu_launch(a, in->format, (flags & FSR1_FLAG_MATH_EXACT) != 0, s2, static_cast<hipStream_t>(stream));
+    e = easu_launch(a, in->format, (flags & FSR1_FLAG_MATH_EXACT) != 0, s2, tall, static_cast<hipStream_t>(stream));
   }
   if (e != hipSuccess) return hip_fail(e, "easu launch");
   return FSR1_OK;
@@ -673,6 +679,8 @@ int fsr1_upscale_plan(const fsr1_image* in, int32_t have_intermediary, const fsr
 void fsr1_debug_fused_run_steps(int32_t steps) { fused_s2_force_steps(steps); }
 // Test hook: -1 = the host's rule, 0 = never, 1 = always take the 512-thread tall tile for one-step exact-2x fused launches.
 void fsr1_debug_fused_tall_tiles(int32_t mode) { fused_s2_force_tall(mode); }
+// Test hook: -1 = the host's rule, 0 = never, 1 = always run exact-2x F EASU launches on 64 x 32 tiles.
+void fsr1_debug_easu_tall_tiles(int32_t mode) { easu_force_tall(mode); }
 
 int fsr1_selftest(uint32_t* failures) {
   if (!failures) return fail(FSR1_ERR_INVALID_ARGUMENT, "selftest: null");

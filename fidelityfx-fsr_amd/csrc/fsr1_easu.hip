@@ -43,14 +43,30 @@ int easu_lds_pitch(int fp_w, bool exact, bool color) {
   return fp_w <= 48 ? 48 : (fp_w <= 56 ? 56 : (fp_w <= 64 ? 64 : 0));
 }
 
-// s2: launch the exact-2x variant (the caller has checked con0 and laid the grid out for the shifted tiles).
-hipError_t easu_launch(const EasuArgs& a, int fmt, bool exact, bool s2, hipStream_t stream) {
+// Exact-2x launches take 64 x 32 tiles (a 35 x 19 footprint per 2048 pixels instead of 35 x 11 per 1024: a seventh less staging; 21.3 KB
+// of LDS, still seven workgroups per CU) when the launch has tiles to spare — batches — or runs beside other frames' launches
+// (FSR1_FLAG_FRAMES_OVERLAP); a single 4K frame alone keeps 64 x 16: half as many workgroups lengthen its tail by more than the
+// staging saves (round 4, profiles/ab_r04/r4c10_tile32.log, EASU us: one 4K frame 42.3 -> 44.5 alone; 16-frame 8K batch 2495 -> 2428;
+// two dispatches on three streams 62.5 -> 60.1 per frame).
+static std::atomic<int> g_easu_forced_tall{-1};  // test hook (fsr1_debug_easu_tall_tiles): -1 = the rule, 0 = never, 1 = always
+void easu_force_tall(int mode) { g_easu_forced_tall.store(mode < 0 ? -1 : (mode ? 1 : 0), std::memory_order_relaxed); }
+bool easu_s2_tall_tiles(int width, int height, int frames, bool overlapped, int cus) {
+  if (const int forced = g_easu_forced_tall.load(std::memory_order_relaxed); forced >= 0) return forced != 0;
+  const long long tiles16 = (long long)((width + 1 + kTileW - 1) / kTileW) * ((height + 1 + kTileH - 1) / kTileH) * frames;
+  return overlapped || tiles16 >= 16ll * 8 * (cus > 0 ? cus : 256);  // sixteen residencies of 64 x 16 tiles (four 4K frames) and up
+}
+
+// s2: launch the exact-2x variant (the caller has checked con0 and laid the grid out for the shifted tiles); tall: on 64 x 32 tiles
+// (default arithmetic only: the EXACT variant's per-pixel form would spill at the seven-wave register budget with the longer loop).
+hipError_t easu_launch(const EasuArgs& a, int fmt, bool exact, bool s2, bool tall, hipStream_t stream) {
   const bool hdr = (a.flags & FSR1_FLAG_HDR_SQUARE) != 0;
   int pitch = s2 ? 0 : easu_lds_pitch(a.fp_w, exact, false);
   if (pitch && easu_lds_bytes(fmt, pitch, a.fp_h) > 40 * 1024) pitch = 0;  // (tall footprints of anisotropic ratios: keep the dense layout's occupancy)
 #define FSR1_LAUNCH_H(F, E, S, P) return hdr ? easu_launch_one<F, E, false, F, S, true, P>(a, stream) : easu_launch_one<F, E, false, F, S, false, P>(a, stream)
+#define FSR1_LAUNCH_T(F, E) return hdr ? easu_launch_one<F, E, false, F, true, true, 0, 32>(a, stream) : easu_launch_one<F, E, false, F, true, false, 0, 32>(a, stream)
 #define FSR1_LAUNCH_E(F)                              \
   do {                                                \
+    if (s2 && tall && !exact) FSR1_LAUNCH_T(F, false); \
     if (s2) {                                         \
       if (exact) FSR1_LAUNCH_H(F, true, true, 0);     \
       FSR1_LAUNCH_H(F, false, true, 0);               \
@@ -69,6 +85,7 @@ hipError_t easu_launch(const EasuArgs& a, int fmt, bool exact, bool s2, hipStrea
     default: return hipErrorInvalidValue;
   }
 #undef FSR1_LAUNCH_E
+#undef FSR1_LAUNCH_T
 #undef FSR1_LAUNCH_H
 }
 

@@ -22,13 +22,16 @@ int easu_lds_pitch(int fp_w, bool exact, bool color);
 // pixel is the same function on the same values: bit-identical to S2 = false (tests/test_gpu_parity.py).
 // PITCH (generic variant only): 0 = dense LDS arrays of the tile's own footprint width; P = the row-interleaved layout with
 // the compile-time pitch P >= a.fp_w (easu_lds_carve_pitched): no LDS address arithmetic per tap row.
-template <int FMT, bool EXACT, bool COLOR = false, int FOUT = FMT, bool S2 = false, bool HDR = false, int PITCH = 0>
+// TH: rows of the output tile (16; 32 for exact-2x launches that are large or overlap other frames' launches, fsr1_easu.hip).
+template <int FMT, bool EXACT, bool COLOR = false, int FOUT = FMT, bool S2 = false, bool HDR = false, int PITCH = 0, int TH = kTileH>
 // amdgpu_waves_per_eu(7, 8): at least seven waves per SIMD, i.e. at most 72 VGPRs.  Only the exact-2x default-arithmetic
 // variant is affected — its row-pair form would take 85 (five waves: 43.7 us) where 68 cost it nothing (41.6 us); every other
 // variant needs fewer than 64 anyway.
 __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(7, 8))) easu_kernel(const EasuArgs a) {
   typedef typename Pixel<FOUT>::T texel_t;
-  constexpr bool kS2 = S2 && kTileH % 16 == 0;  // (other tile heights are tuning builds: the host never selects S2 for them)
+  static_assert(TH % 16 == 0, "a wave filters two quad rows per 16 tile rows");
+  constexpr int kTileH = TH;  // (shadows the default tile height)
+  constexpr bool kS2 = S2;
   constexpr int kS2W = kTileW / 2 + 3, kS2H = kTileH / 2 + 3;  // footprint of every exact-2x tile
   extern __shared__ __attribute__((aligned(16))) char smem[];
   static_assert(!(S2 && PITCH), "the exact-2x variant has a compile-time footprint of its own");
@@ -158,12 +161,12 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(7
   }
 }
 
-template <int FMT, bool EXACT, bool COLOR, int FOUT, bool S2 = false, bool HDR = false, int PITCH = 0>
+template <int FMT, bool EXACT, bool COLOR, int FOUT, bool S2 = false, bool HDR = false, int PITCH = 0, int TH = kTileH>
 hipError_t easu_launch_one(const EasuArgs& a, hipStream_t stream) {
   const dim3 grid((unsigned)(a.tiles_x * a.tiles_y * a.frames)), block(kThreads);
   const size_t lds = easu_lds_bytes(FMT, PITCH ? PITCH : a.fp_w, a.fp_h);
-  if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&easu_kernel<FMT, EXACT, COLOR, FOUT, S2, HDR, PITCH>), lds); e != hipSuccess) return e;
-  hipLaunchKernelGGL((easu_kernel<FMT, EXACT, COLOR, FOUT, S2, HDR, PITCH>), grid, block, lds, stream, a);
+  if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&easu_kernel<FMT, EXACT, COLOR, FOUT, S2, HDR, PITCH, TH>), lds); e != hipSuccess) return e;
+  hipLaunchKernelGGL((easu_kernel<FMT, EXACT, COLOR, FOUT, S2, HDR, PITCH, TH>), grid, block, lds, stream, a);
   return hipGetLastError();
 }
 

@@ -282,8 +282,9 @@ int fsr1_upscale_plan(const fsr1_image* in, int32_t have_intermediary, const fsr
  * back, the next dispatch ramps up; measured on MI355X, profiles/ab_r04/r4c1_fused_trace.log: a fused 4K launch is 59.6 us
  * from first to last instruction and 65 us per launch back to back).  A pipeline owns N non-blocking streams and N
  * EASU -> RCAS intermediaries and sends frame i to stream i mod N: the tail of one frame overlaps the head of the next.
- * Measured with N = 2 (r4c2_two_stream.log): 1080p -> 4K two dispatches 65.6 -> 60.2 us per frame, fused launch 60.5 -> 56.4,
- * 1440p -> 4K 77.9 -> 70.7, 540p -> 1080p 25.8 -> 15.7; N = 3 adds nothing.  The reference's sample has one graphics queue and
+ * Measured (profiles/ab_r04/r4c11_streams_sweep.log, us per frame, N = 1 / 2 / 3 / 4): 1080p -> 4K two dispatches 67.6 / 61.7 / 59.8 /
+ * 64.0, fused launch 63.0 / 54.7 / 54.4 / 59.0, 1440p -> 4K 79.8 / 71.3 / 70.9 / 74.6, 540p -> 1080p two dispatches 28.7 / 20.4 / 17.1 /
+ * 22.0: N = 3 is never worse than 2 and what bench.py and the runner default to; 4 loses.  The reference's sample has one graphics queue and
  * no counterpart; this is what its async-compute note (FSR_Filter.cpp:101 ff. run inside the frame's command list) leaves to
  * the engine.  The images of submissions that may overlap (the last N) must not alias; a pipeline is driven by one host thread
  * at a time.  fork / join order the pipeline's streams against a stream of the caller's.
@@ -326,6 +327,8 @@ void fsr1_debug_fused_run_steps(int32_t steps);
 /* ... and the tile shape of its one-step launches: -1 = the host's rule (the 62 x 30 tile of a 512-thread workgroup for frames that
  * fill the chip, the 62 x 14 tile of a 256-thread one otherwise), 0 = never the tall tile, 1 = always.  Same image either way. */
 void fsr1_debug_fused_tall_tiles(int32_t mode);
+/* ... and of exact-2x EASU launches (F arithmetic): 64 x 32 tiles for large or overlapped launches, 64 x 16 otherwise; -1 / 0 / 1 as above. */
+void fsr1_debug_easu_tall_tiles(int32_t mode);
 
 /* HIP-event stopwatch on a caller stream (used by the bench so that kernel time is measured on the
  * very stream the kernels run on).  Handles are opaque. */

@@ -22,7 +22,7 @@
  * fsr1_rcas_dispatch_band, or with --pipeline fused the single launch fsr1_easu_rcas_fused_dispatch_band); still no image
  * byte crosses a link.
  *
- * --streams S (default 2): every GPU sends its steps through an fsr1_pipeline of S HIP streams (include/fsr1_hip.h, "Frame
+ * --streams S (default 3): every GPU sends its steps through an fsr1_pipeline of S HIP streams (include/fsr1_hip.h, "Frame
  * pipeline"): step i on stream i mod S with that stream's own intermediary, so the tail of one step overlaps the head of the next
  * (a kernel boundary costs ~5 us of an otherwise idle chip).  --streams 1 is the single in-order stream of rounds 1-3.
  *
@@ -395,13 +395,13 @@ static void usage(void) {
        "                   [--stages BITS] [--grain AMOUNT]   (colour stages: 1 SRTM, 2 grain, 4 SRTM inverse, 8/16 TEPD 8/10-bit)\n"
        "                   [--ring R]   (input / output sets to rotate over; default: more than 1 GiB, 4 x the Infinity Cache)\n"
        "                   [--bands]    (one frame stream split into row bands over the GPUs instead of frames per GPU)\n"
-       "                   [--streams S] (HIP streams per GPU the steps alternate over, default 2; 1 = one in-order stream)\n"
+       "                   [--streams S] (HIP streams per GPU the steps alternate over, default 3; 1 = one in-order stream)\n"
        "                   [--dry-run [--dry-fail RANK]]   (the N-thread host side without devices or RCCL: shards, plan, barrier, abort path, JSON)\n"
        "defaults: 1 GPU, 1 frame per GPU, 1920x1080 -> 3840x2160, 100 steps, 10 warmup, two-pass, f, 0.25 stops");
 }
 
 int main(int argc, char** argv) {
-  options_t o = {1, 0, 1920, 1080, 3840, 2160, 100, 10, 0, 0, 0u, 0.25f, 0u, 0.25f, 0, 0, 2, 0, -1};
+  options_t o = {1, 0, 1920, 1080, 3840, 2160, 100, 10, 0, 0, 0u, 0.25f, 0u, 0.25f, 0, 0, 3, 0, -1};
   for (int i = 1; i < argc; ++i) {
     const char* a = argv[i];
     const char* v = i + 1 < argc ? argv[i + 1] : NULL;

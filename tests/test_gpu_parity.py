@@ -679,3 +679,35 @@ def test_selftest_binary32_rcp_ieee_over_all_operands(fsr):
     t0 = time.perf_counter()
     assert fsr.selftest() == 0
     assert time.perf_counter() - t0 < 30.0  # 2^32 operands take about a second on an MI355X
+
+
+@pytest.mark.parametrize("shape", [(97, 160), (31, 75), (64, 40), (70, 9), (1, 1), (200, 31), (33, 17)], ids=lambda s: "%dx%d" % s)
+def test_easu_exact_2x_tall_tiles(fsr, shape):
+    """Exact-2x EASU launches that are large, or that overlap other frames' launches, run on 64 x 32 tiles (easu_kernel<..., TH = 32>):
+    forced here on small ragged images and batches — bit-identical to the 64 x 16 tiles and to the generic kernel, for the default
+    and the EXACT arithmetic, RGBA16F / RGBA32F / RGBA8 storage, the HDR square, and with the overlap hint given by hand."""
+    iw, ih = shape
+    ow, oh = 2 * iw, 2 * ih
+    n = 2
+    lib = fsr.load()
+    src16 = dev(np.stack([frames.synthetic_frame(iw, ih, k=80 + f, dtype=np.float16) for f in range(n)]))
+    for src in (src16, src16.float(), (src16.float().clamp(0, 1) * 255 + 0.5).to(torch.uint8)):
+        for flags in (0, fsr.FLAG_MATH_EXACT, fsr.FLAG_HDR_SQUARE | fsr.FLAG_OUTPUT_STREAMING):
+            lib.fsr1_debug_easu_tall_tiles(0)
+            want = torch.zeros(n, oh, ow, 4, dtype=src.dtype, device="cuda")
+            fsr.easu(src, want, flags=flags)
+            gen = torch.zeros_like(want)
+            fsr.easu(src, gen, flags=flags | fsr.FLAG_NO_FAST_PATHS)
+            lib.fsr1_debug_easu_tall_tiles(1)
+            try:
+                big = torch.full((n, oh + 1, ow + 5, 4), 7, dtype=src.dtype, device="cuda")
+                got = big[:, :oh, :ow]
+                fsr.easu(src, got, flags=flags)
+                torch.cuda.synchronize()
+            finally:
+                lib.fsr1_debug_easu_tall_tiles(-1)
+            assert bool((big[:, oh:] == 7).all()) and bool((big[:, :, ow:] == 7).all()), "wrote outside the output view"
+            assert torch.equal(got, want) and torch.equal(gen, want), (str(src.dtype), flags)
+            hint = torch.zeros_like(want)
+            fsr.easu(src, hint, flags=flags | fsr.FLAG_FRAMES_OVERLAP)  # the rule's own choice under the overlap hint: tall
+            assert torch.equal(hint, want), (str(src.dtype), flags, "overlap hint")

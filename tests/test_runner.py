@@ -69,7 +69,7 @@ def test_runner_on_gpu(runner, pipeline):
     assert d["steps"] == 20 and d["warmup"] == 3 and d["scaling"] == "weak" and d["higher_is_better"] is True
     assert d["world_size_seen"] == 1 and len(d["per_rank_seconds"]) == 1 and abs(d["ms_per_step"] - d["seconds"] * 1e3 / 20) < 1e-3
     assert d["pipeline_run"] == {"two-pass": "two-pass", "fused": "fused", "easu": "easu", "auto": "fused"}[pipeline]
-    assert d["streams"] == 2 and d["intermediary"] == ("one per stream" if pipeline == "two-pass" else "none")  # default: steps alternate over two streams
+    assert d["streams"] == 3 and d["intermediary"] == ("one per stream" if pipeline == "two-pass" else "none")  # default: steps alternate over three streams
 
 
 @pytest.mark.gpu

@@ -31,6 +31,8 @@ def child(args):
         lib.fsr1_debug_fused_run_steps(int(os.environ["FSR1_FUSED_S2_STEPS"]))
     if os.environ.get("FSR1_FUSED_S2_TALL") and hasattr(lib, "fsr1_debug_fused_tall_tiles"):
         lib.fsr1_debug_fused_tall_tiles(int(os.environ["FSR1_FUSED_S2_TALL"]))
+    if os.environ.get("FSR1_EASU_TALL") and hasattr(lib, "fsr1_debug_easu_tall_tiles"):
+        lib.fsr1_debug_easu_tall_tiles(int(os.environ["FSR1_EASU_TALL"]))
     dev = torch.device("cuda", 0)
     flags = {"f": 0, "exact": fsr.FLAG_MATH_EXACT, "h": fsr.FLAG_MATH_PACKED_FP16}[args.math]
     if args.no_fast_paths:
