@@ -14,6 +14,9 @@ fsr = importlib.import_module("fidelityfx-fsr_amd")
 lib = fsr.load()
 dev = torch.device("cuda", 0)
 TAG = os.path.basename(os.environ.get("FSR1_HIP_LIB", "tree"))
+if os.environ.get("FSR1_EASU_TALL"):
+    lib.fsr1_debug_easu_tall_tiles(int(os.environ["FSR1_EASU_TALL"]))
+QUICK = os.environ.get("SWEEP_QUICK") == "1"  # three streams only, the F two-dispatch workloads
 
 
 def rate(pipe, fn, n):
@@ -38,7 +41,7 @@ def run(in_w, in_h, out_w, out_h, frames, flags, fused, what, n):
     dsts = [torch.empty(frames, out_h, out_w, 4, dtype=torch.float16, device=dev) for _ in range(ring)]
     row = []
     for rep in range(2):
-        for n_streams in (1, 2, 3, 4):
+        for n_streams in ((3,) if QUICK else (1, 2, 3, 4)):
             pipe = fsr.Pipeline(n_streams)
             row.append("%d: %.2f" % (n_streams, rate(pipe, lambda i: pipe.upscale(srcs[i % ring], dsts[i % ring], fused=fused, flags=flags), n)))
             pipe.close()
@@ -50,7 +53,11 @@ def run(in_w, in_h, out_w, out_h, frames, flags, fused, what, n):
 if __name__ == "__main__":
     H = fsr.FLAG_MATH_PACKED_FP16
     run(1920, 1080, 3840, 2160, 1, 0, 0, "two dispatches", 2000)
-    if TAG == "tree":
+    if QUICK:
+        run(2560, 1440, 3840, 2160, 1, 0, 0, "two dispatches", 2000)
+        run(2560, 1440, 3840, 2160, 8, 0, 0, "two dispatches", 200)
+        run(3840, 2160, 7680, 4320, 4, 0, 0, "two dispatches", 100)
+    elif TAG == "tree":
         run(1920, 1080, 3840, 2160, 1, 0, 1, "fused", 2000)
         run(1920, 1080, 3840, 2160, 1, H, 0, "two dispatches H", 1500)
         run(2560, 1440, 3840, 2160, 1, 0, 0, "two dispatches", 2000)

@@ -15,20 +15,20 @@ NOTE="Round 4, BASELINE configs[0] shape: fp32 FsrEasuF, EASU only, RGBA32F stor
 NOTE="Round 4, 1.5x single frame" tools/gpu_profile.sh r04_1440p_to_4k_two-pass --workload 1440p_to_4k $P
 STEPS=100 NOTE="Round 4, BASELINE configs[2] per-GPU shard (8 frames per launch)" tools/gpu_profile.sh r04_1440p_to_4k_x8_two-pass --workload 1440p_to_4k_x8 $P
 STEPS=40 PMC_STEPS=6 NOTE="Round 4, BASELINE configs[4] per-GPU shard as ONE fused launch (what auto runs at exactly 2x)" tools/gpu_profile.sh r04_4k_to_8k_x16_fused --workload 4k_to_8k_x16 --pipeline fused $P
-# the pipelined regime: kernel-trace stats only (durations include the overlap with the neighbouring frame's kernels)
+# the pipelined regime (three streams, the default): kernel-trace stats only — durations include the overlap with the neighbouring frames
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_r04_pipelined -o r -- python $OLDPWD/bench.py --no-cpu-baseline --no-cold-rcas --no-also --steps 300 --warmup 30 > /tmp/prof_r04_pipelined.log 2>&1
 cd $OLDPWD
-find /tmp/prof_r04_pipelined -name '*kernel_stats.csv' | head -1 | xargs -I{} cp {} gpurun_out/profiles/r04_1080p_to_4k_two-pass_two_streams_kernel_stats.csv
-grep -h '^{' /tmp/prof_r04_pipelined.log | tail -1 > gpurun_out/profiles/r04_1080p_to_4k_two-pass_two_streams.line
+find /tmp/prof_r04_pipelined -name '*kernel_stats.csv' | head -1 | xargs -I{} cp {} gpurun_out/profiles/r04_1080p_to_4k_two-pass_pipelined_kernel_stats.csv
+grep -h '^{' /tmp/prof_r04_pipelined.log | tail -1 > gpurun_out/profiles/r04_1080p_to_4k_two-pass_pipelined.line
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_r04_pipelined_f -o r -- python bench.py --no-cpu-baseline --no-cold-rcas --no-also --pipeline fused --steps 300 --warmup 30 > /tmp/prof_r04_pipelined_f.log 2>&1
-find /tmp/prof_r04_pipelined_f -name '*kernel_stats.csv' | head -1 | xargs -I{} cp {} gpurun_out/profiles/r04_1080p_to_4k_fused_two_streams_kernel_stats.csv
-grep -h '^{' /tmp/prof_r04_pipelined_f.log | tail -1 > gpurun_out/profiles/r04_1080p_to_4k_fused_two_streams.line
+find /tmp/prof_r04_pipelined_f -name '*kernel_stats.csv' | head -1 | xargs -I{} cp {} gpurun_out/profiles/r04_1080p_to_4k_fused_pipelined_kernel_stats.csv
+grep -h '^{' /tmp/prof_r04_pipelined_f.log | tail -1 > gpurun_out/profiles/r04_1080p_to_4k_fused_pipelined.line
 python bench.py > gpurun_out/r04_bench_default.json 2> gpurun_out/r04_bench_default.err
 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/r04_bench_k20.json 2> gpurun_out/r04_bench_k20.err
 cut -c1-200 gpurun_out/r04_bench_default.json; cut -c1-200 gpurun_out/r04_bench_k20.json
 R=runner/fsr1_runner; O=gpurun_out/r04_runner_c_host.log; : > $O
-for S in 2 1; do
+for S in 3 1; do
 timeout 300 $R --gpus 1 --steps 2000 --warmup 100 --streams $S >> $O 2>/dev/null
 timeout 300 $R --gpus 1 --steps 2000 --warmup 100 --pipeline auto --streams $S >> $O 2>/dev/null
 timeout 300 $R --gpus 1 --steps 2000 --warmup 100 --math h --streams $S >> $O 2>/dev/null
