@@ -386,7 +386,8 @@ def main():
     # is ONE buffer reused by every step, as the sample's single intermediary texture is (FSR_Filter.cpp:70-86): for one 4K
     # frame it stays in the Infinity Cache between the two passes and between steps (DESIGN.md section 5 has the sensitivity:
     # rotating the intermediary as well costs 2-3 %).
-    ring = args.ring or max(2, -(-(1 << 30) // (in_bytes + out_bytes)))
+    # (at least one set more than there are streams: the outputs of steps that may be in flight together must not alias)
+    ring = max(args.ring or max(2, -(-(1 << 30) // (in_bytes + out_bytes))), args.streams + 1 if args.streams > 1 else 1)
 
     # synthetic frames: a few distinct numpy frames uploaded once, then varied on-device per ring slot
     def upload(k):

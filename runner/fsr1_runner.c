@@ -246,6 +246,7 @@ static int worker_body(worker_t* w) {
     ring = (int)(((size_t)1024u * 1024u * 1024u + set_bytes - 1) / set_bytes);
     if (ring < 2) ring = 2;
   }
+  if (o->streams > 1 && ring < o->streams + 1) ring = o->streams + 1;  /* the outputs of steps that may be in flight together must not alias */
   w->ring = ring;
   if (nf > 0) {
     HIP_OK(w, hipMalloc(&w->d_in, in_frame * nf * ring));
