@@ -350,7 +350,11 @@ static int easu_dispatch_impl(const fsr1_image* in, const fsr1_image* out, const
   a.tiles_x = (out->width + kTileW - 1) / kTileW;
   a.tiles_y = (out->height + kTileH - 1) / kTileH;
   a.frames = out->frames;
-  a.flags = resolve_output_policy(flags, false);  // RCAS normally follows: keep the intermediary cached
+  // RCAS normally follows: keep the intermediary cached — unless it is far larger than the 256 MB Infinity Cache anyway (batches):
+  // then plain stores only leave dirty lines for the kernel's end to write back (round 4, 8-frame 1440p -> 4K batch, 531 MB: two
+  // dispatches 610-613 -> 600-605 us; one 4K frame, 66 MB, the other way: 65.8 -> 70.5; profiles/ab_r04/r4c17_easu_streaming_stores.log)
+  const bool beyond_cache = (unsigned long long)a.out.pitch * (unsigned long long)out->height * (unsigned long long)out->frames > (512ull << 20);
+  a.flags = resolve_output_policy(flags, beyond_cache);
   // Exact 2x with the viewport covering the input — con0 = {1/2, 1/2, -1/4, -1/4}, what FsrEasuCon gives for
   // out = 2 * in — takes the variant whose lanes own 2x2 output quads; its tiles are shifted by one pixel, hence one
   // more tile per axis when the size is a multiple of the tile, and the footprint of a tile is 64/2+3 x 16/2+3 texels.

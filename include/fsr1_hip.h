@@ -108,7 +108,8 @@ enum {
   /* Store policy of the pass's output image.  STREAMING: non-temporal stores — the image is not read again soon, so it
    * should not displace what is (measured on MI355X at 4K: RCAS 30.9 -> 25.7 us, two dispatches 70.2 -> 67.5 us).
    * CACHED: plain stores — a reader follows (the EASU -> RCAS intermediary).  Defaults: EASU CACHED (RCAS normally
-   * follows), RCAS and the fused launch STREAMING (their output is the pipeline's last image); fsr1_upscale sets
+   * follows; STREAMING when the image is larger than 512 MB — twice the Infinity Cache: nothing would keep it anyway), RCAS and the
+   * fused launch STREAMING (their output is the pipeline's last image); fsr1_upscale sets
    * STREAMING on whichever pass writes `out`.  The pixels stored are the same either way. */
   FSR1_FLAG_OUTPUT_STREAMING = 1u << 9,
   FSR1_FLAG_OUTPUT_CACHED = 1u << 10,
