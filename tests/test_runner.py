@@ -84,12 +84,19 @@ def test_runner_with_colour_stages(runner):
 
 @pytest.mark.gpu
 def test_runner_packed_fp16_and_ring(runner):
-    """--math h drives FsrEasuH / FsrRcasH from the C host; --ring rotates the steps over several frame sets."""
+    """--math h drives FsrEasuH / FsrRcasH from the C host; --ring rotates the steps over several frame sets — at least one more than
+    there are streams, so that the outputs of steps in flight together never alias (a smaller request is raised)."""
     out = subprocess.run([runner, "--gpus", "1", "--frames", "2", "--in", "640x360", "--out", "1280x720", "--steps", "12",
-                          "--warmup", "2", "--math", "h", "--ring", "3"], capture_output=True, text=True, timeout=1200)
+                          "--warmup", "2", "--math", "h", "--ring", "5"], capture_output=True, text=True, timeout=1200)
     assert out.returncode == 0, out.stdout + out.stderr
     d = json.loads(out.stdout.strip().splitlines()[-1])
-    assert d["math"] == "h" and d["ring"] == 3 and d["frames"] == 24 and d["value"] > 500.0
+    assert d["math"] == "h" and d["ring"] == 5 and d["streams"] == 3 and d["frames"] == 24 and d["value"] > 500.0
+    out = subprocess.run([runner, "--gpus", "1", "--frames", "2", "--in", "640x360", "--out", "1280x720", "--steps", "12",
+                          "--warmup", "2", "--ring", "2"], capture_output=True, text=True, timeout=1200)
+    assert out.returncode == 0 and json.loads(out.stdout.strip().splitlines()[-1])["ring"] == 4  # three streams: four sets
+    out = subprocess.run([runner, "--gpus", "1", "--frames", "2", "--in", "640x360", "--out", "1280x720", "--steps", "12",
+                          "--warmup", "2", "--ring", "2", "--streams", "1"], capture_output=True, text=True, timeout=1200)
+    assert out.returncode == 0 and json.loads(out.stdout.strip().splitlines()[-1])["ring"] == 2
     fused = subprocess.run([runner, "--gpus", "1", "--frames", "1", "--in", "320x180", "--out", "640x360", "--steps", "5", "--warmup", "1",
                             "--math", "h", "--pipeline", "fused"], capture_output=True, text=True, timeout=1200)
     assert fused.returncode == 0, fused.stdout + fused.stderr
