@@ -91,6 +91,107 @@ def median(xs):
     return xs[n // 2] if n % 2 else 0.5 * (xs[n // 2 - 1] + xs[n // 2])
 
 
+class Telemetry:
+    """Shader clock and package power of ONE GPU, sampled by a host thread from the amdgpu driver's sysfs files while the timed
+    regions run (Next 3a: the F kernels run at the package power cap, so an 8-GPU curve is decided by the chassis as
+    much as by the code — the line has to say what clock and power every rank saw).  Files, under the device's PCI node
+    (/sys/bus/pci/devices/<domain:bus:dev.fn>/hwmon/hwmon*/): freq1_input (sclk, Hz), power1_average or power1_input (uW).
+    Everything is best effort: a file that is missing or unreadable leaves that figure null; the run is never failed by it."""
+
+    def __init__(self, torch, dev_index, period=0.002):
+        import glob
+        import threading
+        self.period = period
+        self.freq = self.power = None
+        self.source = None
+        self.samples = []     # (t, mhz or None, watts or None)
+        self.spans = {}       # label -> [(t0, t1), ...]
+        self._open = {}
+        self._stop = threading.Event()
+        self._thread = None
+        try:
+            node = None
+            try:
+                p = torch.cuda.get_device_properties(dev_index)
+                bdf = "%04x:%02x:%02x.0" % (p.pci_domain_id, p.pci_bus_id, p.pci_device_id)
+                if os.path.isdir("/sys/bus/pci/devices/" + bdf):
+                    node, self.source = "/sys/bus/pci/devices/" + bdf, "sysfs hwmon of " + bdf
+            except Exception:
+                pass
+            if node is None:  # no PCI ids from the runtime: the dev_index-th AMD GPU with a hwmon node, in PCI order
+                cands = sorted(os.path.realpath(c) for c in glob.glob("/sys/class/drm/card*/device")
+                               if open(os.path.join(c, "vendor")).read().strip() == "0x1002" and glob.glob(os.path.join(c, "hwmon", "hwmon*")))
+                cands = sorted(set(cands))
+                if dev_index < len(cands):
+                    node, self.source = cands[dev_index], "sysfs hwmon of %s (device %d in PCI order)" % (os.path.basename(cands[dev_index]), dev_index)
+            if node:
+                for hw in sorted(glob.glob(os.path.join(node, "hwmon", "hwmon*"))):
+                    f = os.path.join(hw, "freq1_input")
+                    if self.freq is None and os.path.exists(f):
+                        self.freq = f
+                    for name in ("power1_average", "power1_input"):
+                        f = os.path.join(hw, name)
+                        if self.power is None and os.path.exists(f) and self._read(f) is not None:
+                            self.power = f
+        except Exception:
+            pass
+        if self.freq or self.power:
+            self._thread = threading.Thread(target=self._run, daemon=True)
+            self._thread.start()
+
+    @staticmethod
+    def _read(path):
+        try:
+            with open(path) as f:
+                return float(f.read().split()[0])
+        except Exception:
+            return None
+
+    def _run(self):
+        while not self._stop.is_set():
+            hz = self._read(self.freq) if self.freq else None
+            uw = self._read(self.power) if self.power else None
+            self.samples.append((time.perf_counter(), hz / 1e6 if hz else None, uw / 1e6 if uw else None))
+            self._stop.wait(self.period)
+
+    def begin(self, label):
+        self._open[label] = time.perf_counter()
+
+    def end(self, label):
+        t0 = self._open.pop(label, None)
+        if t0 is not None:
+            self.spans.setdefault(label, []).append((t0, time.perf_counter()))
+
+    def close(self):
+        self._stop.set()
+        if self._thread is not None:
+            self._thread.join(timeout=1.0)
+
+    def summary(self, label):
+        """(median MHz, mean W, samples) over the spans recorded under `label`; None where nothing was read."""
+        spans = self.spans.get(label, [])
+        sel = [s for s in self.samples if any(t0 <= s[0] <= t1 for t0, t1 in spans)]
+        mhz = [s[1] for s in sel if s[1]]
+        w = [s[2] for s in sel if s[2]]
+        return (round(median(mhz), 0) if mhz else None, round(sum(w) / len(w), 0) if w else None, len(sel))
+
+
+def gather_pairs(a, b, device):
+    """Every rank's (a, b) in rank order — per-rank clock and power; NaN stands for "not read" (one counters-only collective)."""
+    import torch
+    import torch.distributed as dist
+    nan = float("nan")
+    mine = torch.tensor([nan if a is None else float(a), nan if b is None else float(b)], dtype=torch.float64, device=device)
+    if not (dist.is_available() and dist.is_initialized()):
+        rows = [mine.tolist()]
+    else:
+        out = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+        dist.all_gather(out, mine)
+        rows = [t.tolist() for t in out]
+    clean = lambda v: None if v != v else v  # noqa: E731
+    return [clean(r[0]) for r in rows], [clean(r[1]) for r in rows]
+
+
 def reduce_regions(region_seconds, device):
     """Elementwise MAX over ranks of the R region times (one counters-only collective): region r of the job took as long as its
     slowest rank's region r."""
@@ -245,11 +346,12 @@ def pmc_traffic(fsr, workload, pipeline, kernel_name, math="f", storage="rgba16f
     return (None, None, None, stale)
 
 
-def cpu_baseline(fsr, in_w, in_h, out_w, out_h, target_seconds=12.0):
+def cpu_baseline(fsr, in_w, in_h, out_w, out_h, target_seconds=12.0, keep=None):
     """The reference path on the host cores: oracle/_ref (the reference headers compiled verbatim; kind
     "reference") when it travelled with the tree, else the plain-C restatement (kind "port"); OpenMP over
     output rows on all host cores; whole frames of the same workload (EASU-F then RCAS-F), repeated until about
-    `target_seconds` of wall time have been spent (a bounded sample: one frame when a frame takes that long)."""
+    `target_seconds` of wall time have been spent (a bounded sample: one frame when a frame takes that long).
+    keep: a dict that receives the first frame (binary16 input, the reference chain's final image) for the line's `parity` block."""
     import numpy as np
     import cpu_oracle
     o = cpu_oracle.ref() if cpu_oracle.have_ref() else cpu_oracle.port()
@@ -265,8 +367,10 @@ def cpu_baseline(fsr, in_w, in_h, out_w, out_h, target_seconds=12.0):
         t1 = time.perf_counter()
         mid = mid.astype(np.float16).astype(np.float32)  # the two-pass intermediary is RGBA16F
         t2 = time.perf_counter()
-        o.rcas_f(mid, rc, 0)
+        out = o.rcas_f(mid, rc, 0)
         t3 = time.perf_counter()
+        if keep is not None and frames == 0:
+            keep.update(input=img.astype(np.float16), want=out, checker=o.kind)
         t_easu += t1 - t0
         t_rcas += t3 - t2
         frames += 1
@@ -311,6 +415,12 @@ def main():
                     help="skip the extra RCAS launches on an HBM-cold image (profiling runs: keeps rocprofv3's per-kernel average to the pipeline's own launches)")
     ap.add_argument("--no-also", action="store_true",
                     help="skip the also_measured pipelines (profiling runs: only the workload's own kernels in the trace)")
+    ap.add_argument("--also", action="store_true",
+                    help="with --gpus N > 1: run the also_measured pipelines as well (default at N > 1: headline regions only, so that no "
+                         "collective runs outside them and one slow rank cannot distort five more sections)")
+    ap.add_argument("--no-latency", action="store_true", help="skip the single-frame latency block (N = 1 only)")
+    ap.add_argument("--no-steady", action="store_true", help="skip the steady-state windows (K steps timed INSIDE a longer stream, fill / drain excluded)")
+    ap.add_argument("--no-parity", action="store_true", help="skip the image-level parity block (N = 1 only; part of the cpu_baseline leg)")
     ap.add_argument("--no-fast-paths", action="store_true", help="FSR1_FLAG_NO_FAST_PATHS: generic kernels only (A/B of the exact-2x variants)")
     ap.add_argument("--rotate-intermediary", action="store_true",
                     help="two-pass: rotate the EASU->RCAS intermediary over the ring as well (round 1's method; default: one reused buffer, as the sample has)")
@@ -388,6 +498,10 @@ def main():
     # rotating the intermediary as well costs 2-3 %).
     # (at least one set more than there are streams: the outputs of steps that may be in flight together must not alias)
     ring = max(args.ring or max(2, -(-(1 << 30) // (in_bytes + out_bytes))), args.streams + 1 if args.streams > 1 else 1)
+    # ... and a multiple of the stream count: step i runs on slot i mod S, so set i mod ring is then always reused by a submission on
+    # the SAME slot — the only reuse the pipeline orders (include/fsr1_hip.h, "Ordering and aliasing")
+    if args.streams > 1:
+        ring = -(-ring // args.streams) * args.streams
 
     # synthetic frames: a few distinct numpy frames uploaded once, then varied on-device per ring slot
     def upload(k):
@@ -438,7 +552,10 @@ def main():
             fsr.easu(srcs[s], dsts[s], con=easu_con, flags=math_flags | fsr.FLAG_OUTPUT_STREAMING, stages=stages)
 
     # --streams S > 1: the same step through an fsr1_pipeline — step i on stream i mod S, that stream's own intermediary
-    pipe = fsr.Pipeline(args.streams) if args.streams > 1 else None
+    # (managed=False: the bare C ABI — the buffers live for the whole run and every timed region is bracketed by synchronizes)
+    pipe = fsr.Pipeline(args.streams, managed=False) if args.streams > 1 else None
+    if pipe is not None and args.pipeline == "two-pass":
+        pipe.reserve(out_bytes)  # no allocation inside a timed region or a graph capture
 
     def piped(flags, fused, use_rcas=True, inputs=None, con_stages=None):
         def fn(i):
@@ -469,6 +586,8 @@ def main():
             torch.cuda.synchronize()
         return t
 
+    tele = Telemetry(torch, dev_index)
+    tele.begin("headline")  # ramp + warm-up + the headline's timed regions: the same pipelined load throughout
     # Device clock ramp (not part of W): an idle MI355X sits at ~100 MHz and needs a few milliseconds of load
     # to reach its working clocks; EASU then runs AT the 1400 W package power cap (sclk ~2.1 of 2.4 GHz), so the
     # steady state is what a frame stream sees.  ~0.2 s of the same steps, untimed.
@@ -514,11 +633,50 @@ def main():
         regions, own_regions = timed(lambda i: g.replay(), args.steps // args.graph)
     else:
         regions, own_regions = timed(step, args.steps, first=args.warmup)
+    tele.end("headline")
     seconds = median(regions)
+
+    def steady(fn, k, stream_of_last):
+        """Steady state: R windows of exactly k steps timed INSIDE one longer run — `lead` steps in front (the pipeline fills), R x k
+        steps, `lead` steps behind (it drains), one fence either side of the whole run and none inside.  Window r is the time from
+        the completion of the step in front of it to the completion of its own last step, taken with HIP events recorded on the
+        streams those steps run on (`stream_of_last()` = the stream the latest submission went to).  What a K-step region adds to
+        this — the first launch's latency and the drain of the last frames, 1-5 % at K = 20 — is what the two figures differ by.
+        Returns the R window times (seconds, MAX over ranks)."""
+        lead = max(k, 4 * args.streams, 8)
+        timers = [fsr.Timer() for _ in range(args.regions)]
+        fence()
+        n = args.warmup
+        for _ in range(lead):
+            fn(n)
+            n += 1
+        for t in timers:
+            t.start(stream_of_last())
+            for _ in range(k):
+                fn(n)
+                n += 1
+            t.stop(stream_of_last())
+        for _ in range(lead):
+            fn(n)
+            n += 1
+        close()
+        return reduce_regions([t.elapsed_ms() * 1e-3 for t in timers], coll_device)
+
+    def last_pipe_stream():
+        return pipe._slot_stream((pipe.next_slot() - 1) % pipe.streams)
+
+    steady_regions = None
+    if not args.no_steady and args.graph == 0:
+        tele.begin("steady")
+        steady_regions = steady(step, args.steps, last_pipe_stream if pipe is not None else (lambda: None))
+        tele.end("steady")
 
     # the same K steps on ONE in-order stream (the method of rounds 1-3): the per-kernel stopwatch below is taken that way, and the
     # line's self-consistency check compares the kernels with THIS step (overlapped steps are shorter than the kernels they contain)
+    tele.begin("one_stream")
     one_regions = timed(step1, args.steps, first=args.warmup)[0] if pipe is not None else regions
+    one_steady = steady(step1, args.steps, lambda: None) if (pipe is not None and steady_regions is not None) else steady_regions
+    tele.end("one_stream")
 
     total = reduce_counters(frames * args.steps, frames * args.steps * out_w * out_h, median(own_regions), coll_device)
     total["seconds"] = seconds  # median over regions of the max over ranks
@@ -595,7 +753,8 @@ def main():
             return dict(one, streams=1, note=note)
         return dict(measure(fn), streams=args.streams, one_stream={k: one[k] for k in ("value", "ms_per_step")}, note=note)
 
-    if args.pipeline == "two-pass" and not args.stages and args.math != "h" and not args.no_also:
+    run_also = not args.no_also and (world == 1 or args.also)  # at N > 1 only the headline regions hold collectives, unless --also
+    if args.pipeline == "two-pass" and not args.stages and args.math != "h" and run_also:
         def fused_step(i):
             fsr.easu_rcas_fused(srcs[i % ring], dsts[i % ring], easu_con=easu_con, rcas_con=rcas_con, flags=math_flags)
         also = {"fused": also_entry(fused_step, "EASU->RCAS in one launch, output bit-identical to the two dispatches (BASELINE configs[3])",
@@ -646,6 +805,56 @@ def main():
                                                               px_per_step=out_w * out_h, fn=pipe and piped(math_flags, 0, inputs=q_in))
             del q_in
 
+    # ---- single-frame latency (N = 1): submit -> completion of ONE frame on a warm, otherwise idle GPU — the reference's actual
+    #      usage, one Upscale per display refresh (SampleRenderer.cpp:705-709), which the pipelined headline does not represent ----
+    latency = None
+    if world == 1 and not args.no_latency and args.pipeline in ("two-pass", "fused") and not args.stages and frames == 1:
+        def lat(submit, n=200, gap=1e-3):
+            for i in range(50):
+                submit(i)
+            torch.cuda.synchronize()
+            host, devt = [], []
+            for i in range(n):
+                if gap:
+                    time.sleep(gap)  # the GPU idles (and starts to drop its clock) like between two display refreshes
+                timer.start()
+                t0 = time.perf_counter()
+                submit(i)
+                timer.stop()
+                torch.cuda.current_stream().synchronize()
+                host.append(time.perf_counter() - t0)
+                devt.append(timer.elapsed_ms() * 1e-3)
+            host.sort()
+            return {"host_us": round(median(host) * 1e6, 1), "host_p90_us": round(host[int(0.9 * (n - 1))] * 1e6, 1), "device_us": round(median(devt) * 1e6, 1)}
+
+        lat_mid = mid if mid is not None else torch.empty_like(dsts[0])
+
+        def two_pass_1(i):
+            fsr.easu(srcs[i % ring], lat_mid, con=easu_con, flags=math_flags)
+            fsr.rcas(lat_mid, dsts[i % ring], con=rcas_con, flags=math_flags)
+
+        def fused_1(i):
+            fsr.easu_rcas_fused(srcs[i % ring], dsts[i % ring], easu_con=easu_con, rcas_con=rcas_con, flags=math_flags)
+        filt = fsr.FSR_Filter()
+        filt.OnCreate(slowFallback=args.math != "h", exact=args.math == "exact", fused="auto")
+        filt.OnCreateWindowSizeDependentResources(srcs[0], dsts[0], out_w, out_h)
+        auto_state = fsr.State(in_w, in_h, bUseRcas=True, rcasAttenuation=0.25)
+        modes = {"two_pass": two_pass_1, "fused": fused_1, "auto": lambda i: filt.Upscale(out_w, out_h, auto_state)}
+        tele.begin("latency")
+        latency = {"frames_per_mode": 200, "idle_gap_ms": 1.0,
+                   "definition": "host_us: time.perf_counter() around submit + hipStreamSynchronize of ONE frame (what an integrator waits), median and p90 of 200 "
+                                 "frames with 1 ms of idle GPU before each; device_us: HIP events on the stream just before / after the frame's launches; "
+                                 "back_to_back: the same without the idle gap (the GPU keeps its clocks)",
+                   "after_1ms_idle": {k: lat(f) for k, f in modes.items()},
+                   "back_to_back": {k: lat(f, gap=0.0) for k, f in modes.items()}}
+        tele.end("latency")
+        filt.OnDestroy()
+
+    # per-rank shader clock and package power during the headline regions (sysfs, best effort) — one counters-only collective
+    tele.close()
+    head_mhz, head_w, head_n = tele.summary("headline")
+    per_rank_mhz, per_rank_watts = gather_pairs(head_mhz, head_w, coll_device)
+
     # algorithmic HBM bytes per launch: EASU in+out, RCAS 2*out, fused in+out
     alg = {"easu": in_bytes + out_bytes, "rcas": 2 * out_bytes, "fused": in_bytes + out_bytes, "color": 2 * out_bytes}
     dominant = max(kern, key=kern.get)
@@ -691,10 +900,15 @@ def main():
             "vs_baseline_ref": "per GPU, vs BASELINE.md §1: EASU+RCAS <= 0.40 ms per 4K frame (<= 0.20 ms per 1440p frame) on RX 6800 XT / RTX 3080 (reference PDF p.9) = >= 20736 (18432) Mpix/s; "
                                "an upper bound on time, measured on other hardware",
             "dtype": "f32" if args.math != "h" else "f16", "data": "synthetic",
+            # which parity class the headline's arithmetic belongs to (include/fsr1_hip.h, FSR1_FLAG_MATH_*):
+            #   F-default: fp32 arithmetic, per stage <= 1 binary16 ULP of the CPU-evaluated FsrEasuF / FsrRcasF; image level: see `parity`
+            #   EXACT: bit-identical to the reference chain;  H: bit-identical to the CPU-evaluated FsrEasuH / FsrRcasH
+            "parity_class": {"f": "F-default", "exact": "EXACT", "h": "H"}[args.math],
             "config": {"workload": "%s: %dx%d -> %dx%d %s, %d frame(s)/step/GPU, %s, math=%s, ring of %d frame sets"
                                    % (args.workload, in_w, in_h, out_w, out_h, args.storage.upper(), frames, args.pipeline, args.math, ring)
                                    + (" (inputs / outputs; one reused intermediary)" if args.pipeline == "two-pass" else ""),
-                       "source_hash": fsr._lib.source_hash(),
+                       "source_hash": fsr._lib.source_hash(), "build_id": fsr._lib.build_id(),
+                       "binary_matches_sources": fsr._lib.build_id() == fsr._lib.source_hash(),
                        "intermediary": None if args.pipeline != "two-pass" else ("one per stream" if pipe is not None else ("rotated" if args.rotate_intermediary else "reused")),
                        "launch": launch_style(), "world_size_seen": dist.get_world_size() if grouped else 1,
                        "collective_backend": (("rccl (torch.distributed 'nccl')" if args.backend == "nccl" else "gloo") if grouped else None),
@@ -714,16 +928,61 @@ def main():
                        "pipeline": args.pipeline, "storage": args.storage, "color_stages": args.stages, "hip_graph_steps": args.graph, "rcas_sharpness_stops": 0.25,
                        "parallelism": "independent frames per GPU, counters-only collective"},
             "per_rank_seconds": [round(t, 6) for t in per_rank_seconds],
+            # shader clock (median MHz) and package power (mean W) every rank's GPU showed during its headline regions (ramp + warm-up +
+            # timed regions), read from the amdgpu driver's sysfs files by a host thread; null where a box does not expose them
+            "per_rank_mhz": per_rank_mhz, "per_rank_watts": per_rank_watts,
+            "telemetry": {"source": tele.source, "samples_rank0": head_n, "period_ms": tele.period * 1e3,
+                          "one_stream": dict(zip(("mhz", "watts", "samples"), tele.summary("one_stream"))),
+                          "steady": dict(zip(("mhz", "watts", "samples"), tele.summary("steady"))),
+                          "latency": dict(zip(("mhz", "watts", "samples"), tele.summary("latency")))},
             "roofline": roof(dominant),
             "kernels": {k: roof(k) for k in kern},
             "pipeline_hbm": {"algorithmic_bytes_per_step": sum(alg[k] for k in kern),
                              "achieved_GBps": round(sum(alg[k] for k in kern) * args.steps / seconds / 1e9, 1)},
         }
+        if steady_regions is not None:
+            def _st(reg):
+                return {"value": round(total["pixels"] / median(reg) / 1e6, 1), "ms_per_step": round(median(reg) * 1e3 / args.steps, 5),
+                        "ms_per_step_min": round(min(reg) * 1e3 / args.steps, 5), "ms_per_step_max": round(max(reg) * 1e3 / args.steps, 5)}
+            line["steady_state"] = dict(_st(steady_regions), windows=args.regions, one_stream=_st(one_steady),
+                                        method="R windows of exactly K steps timed with HIP events INSIDE one longer run (K or more steps in front and behind, no "
+                                               "fence inside): the pipeline's fill and drain, which a K-step region includes (1-5 % at K = 20), are excluded")
+        if latency:
+            line["latency_us"] = latency
         if also:
             line["also_measured"] = also
+        elif world > 1 and not args.no_also:
+            line["also_measured"] = None
+            line["also_measured_note"] = "skipped at n_gpus > 1 (only the headline regions hold collectives); pass --also to run them"
         check_stopwatch(line)  # sum of kernel times <= the step that contains them, or the line says "stopwatch_suspect"
         if world == 1 and not args.no_cpu_baseline and args.pipeline != "color" and not args.stages:
-            line["cpu_baseline"] = cpu_baseline(fsr, in_w, in_h, out_w, out_h)
+            kept = {}
+            line["cpu_baseline"] = cpu_baseline(fsr, in_w, in_h, out_w, out_h, keep=kept)
+            if not args.no_parity and kept and args.storage == "rgba16f" and args.math in ("f", "exact") and args.pipeline in ("two-pass", "fused"):
+                # Image-level parity of THIS workload's arithmetic against the reference chain the cpu_baseline leg just evaluated
+                # (FsrEasuF -> RTNE binary16 -> FsrRcasF, ffx_fsr1.h:315-437, :684-769): the final image of the two dispatches, the fused
+                # launch and a pipelined frame, as a binary16-ULP histogram over R, G, B.  The oracle is the checker here, never the
+                # thing measured; the full table over every BASELINE shape and true-ratio preset is tests/test_gpu_image_parity.py ->
+                # profiles/r05_image_parity.json.
+                import image_parity
+                p_src = torch.from_numpy(kept["input"]).to(device)
+                p_mid = torch.empty(out_h, out_w, 4, dtype=torch.float16, device=device)
+                p_out = {k: torch.empty_like(p_mid) for k in ("two_dispatch", "fused", "pipelined")}
+                fsr.easu(p_src, p_mid, con=easu_con, flags=math_flags)
+                fsr.rcas(p_mid, p_out["two_dispatch"], con=rcas_con, flags=math_flags)
+                fsr.easu_rcas_fused(p_src, p_out["fused"], easu_con=easu_con, rcas_con=rcas_con, flags=math_flags)
+                pp = fsr.Pipeline(max(args.streams, 2))
+                for _ in range(pp.streams):
+                    pp.upscale(p_src, p_out["pipelined"], sharpness=0.25, fused=0 if args.pipeline == "two-pass" else 1, flags=math_flags)
+                    pp.synchronize()
+                pp.close()
+                torch.cuda.synchronize()
+                line["parity"] = {"against": "the reference chain FsrEasuF -> RTNE binary16 -> FsrRcasF on the same frame, evaluated by the cpu_baseline leg (kind: %s)" % kept["checker"],
+                                  "unit": "binary16 ULP of the final image, R/G/B values", "gate": "no NaN, >= 99 % within 1 ULP (tests/test_gpu_image_parity.py); EXACT: 0 differing values",
+                                  "all_shapes": "profiles/r05_image_parity.json"}
+                for k, t in p_out.items():
+                    h = image_parity.ulp_histogram(t, kept["want"])
+                    line["parity"][k] = {kk: h[kk] for kk in ("max_ulp", "hist", "frac_bit_equal", "frac_within_1ulp", "nan_in_output")}
         print(json.dumps(line), flush=True)
     if pipe is not None:
         pipe.close()

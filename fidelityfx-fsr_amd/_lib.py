@@ -8,6 +8,8 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FSR1_HIP_LIB") or os.path.join(_HERE, "libfsr1_hip.so")  # env override: tuning experiments only
+# the same objects + the launch-shape test hooks of include/fsr1_hip_test.h (tests and tuning runs only; see test_hooks())
+TEST_LIB_PATH = LIB_PATH[:-3] + "_test.so" if LIB_PATH.endswith(".so") else LIB_PATH + "_test"
 
 _U32P = ctypes.POINTER(ctypes.c_uint32)
 _F = ctypes.c_float
@@ -76,6 +78,8 @@ SYMBOLS = {
     "fsr1_upscale_plan": (ctypes.c_int, [_IMG, ctypes.c_int32, _IMG, ctypes.POINTER(fsr1_params), ctypes.c_int32]),
     "fsr1_pipeline_create": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int32]),
     "fsr1_pipeline_upscale": (ctypes.c_int, [ctypes.c_void_p, _IMG, _IMG, ctypes.POINTER(fsr1_params), _STG]),
+    "fsr1_pipeline_reserve": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_size_t]),
+    "fsr1_pipeline_next_slot": (ctypes.c_int, [ctypes.c_void_p]),
     "fsr1_pipeline_fork": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     "fsr1_pipeline_join": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     "fsr1_pipeline_synchronize": (ctypes.c_int, [ctypes.c_void_p]),
@@ -86,9 +90,7 @@ SYMBOLS = {
     "fsr1_version": (ctypes.c_int, []),
     "fsr1_device_count": (ctypes.c_int, []),
     "fsr1_selftest": (ctypes.c_int, [_U32P]),
-    "fsr1_debug_fused_run_steps": (None, [ctypes.c_int32]),
-    "fsr1_debug_fused_tall_tiles": (None, [ctypes.c_int32]),
-    "fsr1_debug_easu_tall_tiles": (None, [ctypes.c_int32]),
+    "fsr1_build_id": (ctypes.c_char_p, []),
     "fsr1_timer_create": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p)]),
     "fsr1_timer_start": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     "fsr1_timer_stop": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
@@ -96,7 +98,15 @@ SYMBOLS = {
     "fsr1_timer_destroy": (ctypes.c_int, [ctypes.c_void_p]),
 }
 
+# include/fsr1_hip_test.h: exported by libfsr1_hip_test.so only
+TEST_SYMBOLS = {
+    "fsr1_debug_fused_run_steps": (None, [ctypes.c_int32]),
+    "fsr1_debug_fused_tall_tiles": (None, [ctypes.c_int32]),
+    "fsr1_debug_easu_tall_tiles": (None, [ctypes.c_int32]),
+}
+
 _lib = None
+_test_lib = None
 
 
 def source_hash():
@@ -106,12 +116,18 @@ def source_hash():
     h = hashlib.sha256()
     root = os.path.dirname(_HERE)
     files = []
-    for d, exts in ((os.path.join(_HERE, "csrc"), (".hip", ".h", ".c", "Makefile")), (os.path.join(root, "include"), (".h", ".hpp"))):
+    for d, exts in ((os.path.join(_HERE, "csrc"), (".hip", ".h", ".c", ".cpp", "Makefile")), (os.path.join(root, "include"), (".h", ".hpp"))):
         files += [os.path.join(d, f) for f in os.listdir(d) if f.endswith(exts)]
     for f in sorted(files):
         h.update(os.path.basename(f).encode() + b"\0")
         h.update(open(f, "rb").read())
     return h.hexdigest()[:16]
+
+
+def build_id():
+    """fsr1_build_id() of the LOADED library: the source hash baked into the binary when it was built.  Equal to source_hash() unless a
+    stale prebuilt binary is running beside newer sources."""
+    return load().fsr1_build_id().decode()
 
 
 def build(force=False):
@@ -120,32 +136,67 @@ def build(force=False):
     if force:
         subprocess.check_call(cmd + ["clean"], stdout=subprocess.DEVNULL)
     subprocess.check_call(cmd, stdout=subprocess.DEVNULL)
-    if not os.path.exists(LIB_PATH):
-        raise RuntimeError("build finished but %s is missing" % LIB_PATH)
+    for path in (LIB_PATH, TEST_LIB_PATH):
+        if not os.path.exists(path):
+            raise RuntimeError("build finished but %s is missing" % path)
+
+
+def _open(path, symbols):
+    if not os.path.exists(path):
+        raise RuntimeError(
+            "%s not found: the HIP extension is not built (run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C fidelityfx-fsr_amd/csrc`). There is no CPU fallback." % path)
+    # One HIP runtime per process: torch wheels bundle their own libamdhip64 (same SONAME as the
+    # system one this library is linked to).  If torch is going to be used it must be loaded first so
+    # that this library binds to the runtime torch's allocator and streams live in.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+    lib = ctypes.CDLL(path)
+    for name, (res, args) in symbols.items():
+        fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    return lib
 
 
 def load():
     """Return the loaded library with prototypes set; raises if it has not been built."""
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise RuntimeError(
-                "%s not found: the HIP extension is not built (run `python -c 'import __graft_entry__ as g; g.build()'` "
-                "or `make -C fidelityfx-fsr_amd/csrc`). There is no CPU fallback." % LIB_PATH)
-        # One HIP runtime per process: torch wheels bundle their own libamdhip64 (same SONAME as the
-        # system one this library is linked to).  If torch is going to be used it must be loaded first so
-        # that this library binds to the runtime torch's allocator and streams live in.
-        try:
-            import torch  # noqa: F401
-        except ImportError:
-            pass
-        lib = ctypes.CDLL(LIB_PATH)
-        for name, (res, args) in SYMBOLS.items():
-            fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
-            fn.restype = res
-            fn.argtypes = args
-        _lib = lib
+        _lib = _open(LIB_PATH, SYMBOLS)
     return _lib
+
+
+def load_test():
+    """libfsr1_hip_test.so: every symbol of the product library plus the fsr1_debug_* launch-shape hooks (include/fsr1_hip_test.h)."""
+    global _test_lib
+    if _test_lib is None:
+        _test_lib = _open(TEST_LIB_PATH, dict(SYMBOLS, **TEST_SYMBOLS))
+    return _test_lib
+
+
+class test_hooks:
+    """`with _lib.test_hooks() as lib:` — inside the block every call of this package (api.py goes through load()) runs in
+    libfsr1_hip_test.so, whose fsr1_debug_* switches `lib` exposes; on exit the switches are back at "the host's rule" and the package
+    is back on the product library.  Tests and tuning runs only: the product library has no such switches."""
+
+    def __enter__(self):
+        global _lib
+        load()
+        self._saved = _lib
+        _lib = load_test()
+        return _lib
+
+    def __exit__(self, *exc):
+        global _lib
+        t = load_test()
+        t.fsr1_debug_fused_run_steps(0)
+        t.fsr1_debug_fused_tall_tiles(-1)
+        t.fsr1_debug_easu_tall_tiles(-1)
+        _lib = self._saved
+        return False
 
 
 class Fsr1Error(RuntimeError):

@@ -361,37 +361,83 @@ class FSR_Filter:
 class Pipeline:
     """fsr1_pipeline: independent frames on alternating HIP streams (include/fsr1_hip.h, "Frame pipeline").  Frame i of a sequence
     of upscale() calls runs on stream i mod `streams` with that stream's own EASU -> RCAS intermediary, so the tail of one frame
-    overlaps the head of the next (a kernel boundary costs ~5 us on MI355X).  The tensors of calls that may overlap — the last
-    `streams` — must not alias; fork() / join() order the pipeline against a torch stream (default: the current one)."""
+    overlaps the head of the next (a kernel boundary costs ~5 us on MI355X).
 
-    def __init__(self, streams=3):
+    The pipeline's streams are HIP streams torch does not know about.  With managed = True (the default) the wrapper closes the two
+    gaps that leaves:
+      * ordering: every submission's stream first waits for what the CURRENT torch stream holds at the time of the call (the producer
+        of `src`, the last consumer of `dst`) — one event, one wait, on that slot's stream only;
+      * lifetime: src / dst / stages stay referenced until the submission has left the device (or join() / synchronize() / close()),
+        so torch's caching allocator cannot hand their memory to a later op on the current stream while a pipeline kernel still uses it.
+    join() (or synchronize()) is still mandatory before the OUTPUTS are consumed on a torch stream.  managed = False is the bare C
+    ABI: the caller forks, joins and keeps tensors alive itself (bench.py: its buffers live for the whole run and it synchronizes
+    around every timed region).
+
+    Aliasing (include/fsr1_hip.h): streams are ordered only within themselves — a tensor may be reused by a later submission only
+    when that submission takes the same slot (next_slot()), or after join() / synchronize(); a ring of buffers whose length is a
+    multiple of `streams`, walked in order, satisfies that by construction."""
+
+    def __init__(self, streams=3, managed=True):
         self._h = ctypes.c_void_p()
         _lib.check(_lib.load().fsr1_pipeline_create(ctypes.byref(self._h), int(streams)))
         self.streams = int(streams)
+        self.managed = bool(managed)
+        self._slot_streams = None
+        self._live = []  # (completion event, tensors) of submissions that may still be on the device
+
+    def _slot_stream(self, slot):
+        import torch
+        if self._slot_streams is None:
+            lib = _lib.load()
+            self._slot_streams = [torch.cuda.ExternalStream(lib.fsr1_pipeline_stream(self._h, i)) for i in range(self.streams)]
+        return self._slot_streams[slot]
+
+    def next_slot(self):
+        """The slot (0 .. streams - 1) the next upscale() runs on."""
+        return int(_lib.load().fsr1_pipeline_next_slot(self._h))
+
+    def reserve(self, bytes_per_stream):
+        """fsr1_pipeline_reserve: size every stream's intermediary now (bytes of the largest output frame or batch), so that no later
+        submission allocates — required before capturing submissions into a graph on a pipeline that has not seen that size yet."""
+        _lib.check(_lib.load().fsr1_pipeline_reserve(self._h, int(bytes_per_stream)))
 
     def upscale(self, src, dst, sharpness=0.25, use_rcas=True, fused=0, flags=0, hdr=False, stages=None, render_size=None):
         """dst = Upscale(src) (FSR_Filter::Upscale, FSR_Filter.cpp:101-141) on the pipeline's next stream; fused: 0 two dispatches, 1 the
         single launch, 2 whichever is faster; render_size: (renderWidth, renderHeight) when smaller than the input resource."""
+        import torch
         i, o = image_of(src), image_of(dst)
         rw, rh = render_size if render_size is not None else (i.width, i.height)
         p = fsr1_params(float(rw), float(rh), int(bool(use_rcas)), float(sharpness), int(bool(hdr)), int(fused) if use_rcas else 0, int(flags))
         sp, _keep = _stages(stages)
+        slot_stream = None
+        if self.managed:
+            slot_stream = self._slot_stream(self.next_slot())
+            slot_stream.wait_stream(torch.cuda.current_stream())  # after the producer of src / the last user of dst on the caller's stream
         _lib.check(_lib.load().fsr1_pipeline_upscale(self._h, ctypes.byref(i), ctypes.byref(o), ctypes.byref(p), sp))
+        if self.managed and not torch.cuda.is_current_stream_capturing():  # (a captured submission runs at replay time: the graph's owner keeps its tensors)
+            while self._live and self._live[0][0].query():  # submissions that have left the device no longer need their tensors held
+                self._live.pop(0)
+            self._live.append((slot_stream.record_event(), (src, dst, stages)))
         return dst
 
     def fork(self, stream=None):
         _lib.check(_lib.load().fsr1_pipeline_fork(self._h, _stream_ptr(stream)))
 
     def join(self, stream=None):
+        """Work submitted to `stream` (default: the current torch stream) afterwards starts only after everything the pipeline holds now.
+        (The tensors of finished submissions are released as later calls notice their completion, or by synchronize() / close().)"""
         _lib.check(_lib.load().fsr1_pipeline_join(self._h, _stream_ptr(stream)))
 
     def synchronize(self):
         _lib.check(_lib.load().fsr1_pipeline_synchronize(self._h))
+        self._live.clear()
 
     def close(self):
         if self._h:
-            _lib.load().fsr1_pipeline_destroy(self._h)
+            _lib.load().fsr1_pipeline_destroy(self._h)  # (synchronizes the pipeline's streams first)
             self._h = ctypes.c_void_p()
+        self._live.clear()
+        self._slot_streams = None
 
     def __del__(self):
         try:

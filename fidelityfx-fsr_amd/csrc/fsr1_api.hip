@@ -14,7 +14,6 @@
 namespace fsr1 {
 hipError_t easu_launch(const EasuArgs& a, int fmt, bool exact, bool s2, bool tall, hipStream_t stream);
 bool easu_s2_tall_tiles(int width, int height, int frames, bool overlapped, int cus);
-void easu_force_tall(int mode);
 size_t easu_lds_bytes(int fmt, int fp_w, int fp_h);
 hipError_t rcas_launch(const RcasArgs& a, int fmt, bool exact, hipStream_t stream);
 void rcas_geometry(int width, int height, int frames, bool overlapped, int* tiles_x, int* tiles_y, int* rows);
@@ -28,8 +27,6 @@ void fused_s2_geometry(int width, int height, int steps, int* tiles_x, int* tile
 int fused_s2_run_steps(int width, int height, int frames, int cus, int wgs_per_cu, bool overlapped);
 hipError_t fused_s2_h_launch(const FusedArgs& a, hipStream_t stream);
 size_t fused_s2_h_lds_bytes();
-void fused_s2_force_steps(int steps);
-void fused_s2_force_tall(int mode);
 size_t fused_h_lds_bytes(int fp_w, int fp_h);
 hipError_t easu_h_launch(const EasuArgs& a, bool s2, hipStream_t stream);
 hipError_t easu_color_launch(const EasuArgs& a, int fin, int fout, bool exact, hipStream_t stream);
@@ -679,13 +676,6 @@ int fsr1_upscale_plan(const fsr1_image* in, int32_t have_intermediary, const fsr
   return plan.pipeline;
 }
 
-// Test hook: force the number of 16-row steps the exact-2x fused launch's workgroups walk (0 = the host's rule).
-void fsr1_debug_fused_run_steps(int32_t steps) { fused_s2_force_steps(steps); }
-// Test hook: -1 = the host's rule, 0 = never, 1 = always take the 512-thread tall tile for one-step exact-2x fused launches.
-void fsr1_debug_fused_tall_tiles(int32_t mode) { fused_s2_force_tall(mode); }
-// Test hook: -1 = the host's rule, 0 = never, 1 = always run exact-2x F EASU launches on 64 x 32 tiles.
-void fsr1_debug_easu_tall_tiles(int32_t mode) { easu_force_tall(mode); }
-
 int fsr1_selftest(uint32_t* failures) {
   if (!failures) return fail(FSR1_ERR_INVALID_ARGUMENT, "selftest: null");
   uint32_t* d = nullptr;
@@ -734,6 +724,36 @@ int fsr1_pipeline_create(fsr1_pipeline** out, int32_t streams) {
   return FSR1_OK;
 }
 
+// Grows slot `slot`'s intermediary to at least `need` bytes, in stream order on the slot's own stream (hipFreeAsync / hipMallocAsync:
+// no host block, no device-wide synchronisation; the old buffer is released after the slot's last submission, the new one exists
+// before its next).  Refused with a clear error while the stream is being captured into a hipGraph: an allocation node inside a
+// captured frame is not what the caller wants replayed — fsr1_pipeline_reserve() before the capture instead.
+static int pipeline_grow(fsr1_pipeline* p, int slot, size_t need, const char* who) {
+  if (p->mid_bytes[slot] >= need) return FSR1_OK;
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipError_t e = hipStreamIsCapturing(p->streams[slot], &cap); e != hipSuccess) return hip_fail(e, "hipStreamIsCapturing");
+  if (cap != hipStreamCaptureStatusNone)
+    return fail(FSR1_ERR_INVALID_ARGUMENT, "%s: stream %d's intermediary (%zu bytes) must grow to %zu bytes while the stream is being captured; "
+                "call fsr1_pipeline_reserve(pipeline, %zu) before the capture begins", who, slot, p->mid_bytes[slot], need, need);
+  if (p->mid[slot]) {
+    if (hipError_t e = hipFreeAsync(p->mid[slot], p->streams[slot]); e != hipSuccess) return hip_fail(e, "hipFreeAsync of the intermediary");
+    p->mid[slot] = nullptr;
+    p->mid_bytes[slot] = 0;
+  }
+  if (hipError_t e = hipMallocAsync(&p->mid[slot], need, p->streams[slot]); e != hipSuccess) return hip_fail(e, "hipMallocAsync of the intermediary");
+  p->mid_bytes[slot] = need;
+  return FSR1_OK;
+}
+
+int fsr1_pipeline_reserve(fsr1_pipeline* p, size_t bytes_per_stream) {
+  if (!p || p->n < 1) return fail(FSR1_ERR_INVALID_ARGUMENT, "pipeline_reserve: null pipeline");
+  if (int dev = -1; hipGetDevice(&dev) != hipSuccess || dev != p->device)
+    return fail(FSR1_ERR_INVALID_ARGUMENT, "pipeline_reserve: the pipeline belongs to device %d, the calling thread's current device is %d", p->device, dev);
+  for (int i = 0; i < p->n; ++i)
+    if (int rc = pipeline_grow(p, i, bytes_per_stream, "pipeline_reserve")) return rc;
+  return FSR1_OK;
+}
+
 int fsr1_pipeline_upscale(fsr1_pipeline* p, const fsr1_image* in, const fsr1_image* out, const fsr1_params* params,
                           const fsr1_color_stages* stages) {
   if (!p || p->n < 1) return fail(FSR1_ERR_INVALID_ARGUMENT, "pipeline_upscale: null pipeline");
@@ -747,16 +767,7 @@ int fsr1_pipeline_upscale(fsr1_pipeline* p, const fsr1_image* in, const fsr1_ima
   const fsr1_image* mid_p = nullptr;
   if (plan.pipeline == 0) {  // two dispatches: this slot's own intermediary, out's format and extent
     const size_t need = (size_t)out->width * pixel_bytes(out->format) * (size_t)out->height * (size_t)out->frames;
-    if (p->mid_bytes[slot] < need) {
-      if (p->mid[slot]) {
-        if (hipError_t e = hipStreamSynchronize(p->streams[slot]); e != hipSuccess) return hip_fail(e, "pipeline_upscale: hipStreamSynchronize");
-        (void)hipFree(p->mid[slot]);
-        p->mid[slot] = nullptr;
-        p->mid_bytes[slot] = 0;
-      }
-      if (hipError_t e = hipMalloc(&p->mid[slot], need); e != hipSuccess) return hip_fail(e, "pipeline_upscale: hipMalloc of the intermediary");
-      p->mid_bytes[slot] = need;
-    }
+    if (int rc = pipeline_grow(p, slot, need, "pipeline_upscale")) return rc;
     mid_img = fsr1_image{p->mid[slot], out->width, out->height, out->format, out->frames, 0, 0};
     mid_p = &mid_img;
   }
@@ -770,6 +781,8 @@ int fsr1_pipeline_upscale(fsr1_pipeline* p, const fsr1_image* in, const fsr1_ima
   p->next = (slot + 1) % p->n;
   return FSR1_OK;
 }
+
+int fsr1_pipeline_next_slot(const fsr1_pipeline* p) { return p && p->n > 0 ? p->next : -1; }
 
 int fsr1_pipeline_fork(fsr1_pipeline* p, void* stream) {
   if (!p) return fail(FSR1_ERR_INVALID_ARGUMENT, "pipeline_fork: null pipeline");
@@ -801,9 +814,10 @@ void* fsr1_pipeline_stream(const fsr1_pipeline* p, int32_t i) { return p && i >=
 int fsr1_pipeline_destroy(fsr1_pipeline* p) {
   if (!p) return FSR1_OK;
   for (int i = 0; i < fsr1_pipeline::kMax; ++i) {
-    if (p->streams[i]) { (void)hipStreamSynchronize(p->streams[i]); (void)hipStreamDestroy(p->streams[i]); }
+    if (p->streams[i]) (void)hipStreamSynchronize(p->streams[i]);
+    if (p->mid[i]) (void)hipFree(p->mid[i]);  // (stream-ordered allocations may be released with hipFree once their stream is idle)
+    if (p->streams[i]) (void)hipStreamDestroy(p->streams[i]);
     if (p->done[i]) (void)hipEventDestroy(p->done[i]);
-    if (p->mid[i]) (void)hipFree(p->mid[i]);
   }
   if (p->fork_ev) (void)hipEventDestroy(p->fork_ev);
   delete p;

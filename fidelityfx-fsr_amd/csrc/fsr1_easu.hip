@@ -27,6 +27,7 @@
 // the result is bit-identical to the CPU-evaluated FsrEasuF; without it the continuous remainder
 // is re-associated (easu_filter in fsr1_device_easu.hpp), which moves the fp32 result by ~1e-6 relative.
 #include "fsr1_easu_kernel.h"
+#include "fsr1_overrides.h"
 
 namespace fsr1 {
 
@@ -48,10 +49,8 @@ int easu_lds_pitch(int fp_w, bool exact, bool color) {
 // (FSR1_FLAG_FRAMES_OVERLAP); a single 4K frame alone keeps 64 x 16: half as many workgroups lengthen its tail by more than the
 // staging saves (round 4, profiles/ab_r04/r4c10_tile32.log, EASU us: one 4K frame 42.3 -> 44.5 alone; 16-frame 8K batch 2495 -> 2428;
 // two dispatches on three streams 62.5 -> 60.1 per frame).
-static std::atomic<int> g_easu_forced_tall{-1};  // test hook (fsr1_debug_easu_tall_tiles): -1 = the rule, 0 = never, 1 = always
-void easu_force_tall(int mode) { g_easu_forced_tall.store(mode < 0 ? -1 : (mode ? 1 : 0), std::memory_order_relaxed); }
 bool easu_s2_tall_tiles(int width, int height, int frames, bool overlapped, int cus) {
-  if (const int forced = g_easu_forced_tall.load(std::memory_order_relaxed); forced >= 0) return forced != 0;
+  if (const int forced = override_easu_s2_tall(); forced >= 0) return forced != 0;  // (csrc/fsr1_overrides.h: -1 in the product library)
   const long long tiles16 = (long long)((width + 1 + kTileW - 1) / kTileW) * ((height + 1 + kTileH - 1) / kTileH) * frames;
   return overlapped || tiles16 >= 16ll * 8 * (cus > 0 ? cus : 256);  // sixteen residencies of 64 x 16 tiles (four 4K frames) and up
 }

@@ -19,6 +19,7 @@
 #include "fsr1_device.h"
 #include "fsr1_device_easu.hpp"
 #include "fsr1_device_rcas.hpp"
+#include "fsr1_overrides.h"
 
 namespace fsr1 {
 
@@ -37,12 +38,10 @@ size_t fused_s2_lds_bytes(int fmt, int waves) {
 // 5: +18 %), four 4K frames or one 8K frame (38 440) gain 4.5 % at S = 4 (2: 1-2 %, 6: 2 %, 8: -1 %), sixteen 8K frames
 // (613 000) gain 6.3 % at S = 8 (6: 5.7 %, 10: 5.9 %, 16: 4.5 %) — so: about five residencies of runs, at most 8 steps.
 constexpr int kFs2MaxSteps = 8;
-// Test hook (fsr1_debug_fused_run_steps, include/fsr1_hip.h): a forced number of steps per run, 0 = the rule below.  Any number gives
-// the same image (tests/test_gpu_parity.py::test_fused_exact_2x_run_steps); tuning runs set it through the same call.
-static std::atomic<int> g_fs2_forced_steps{0};
-void fused_s2_force_steps(int steps) { g_fs2_forced_steps.store(steps < 0 ? 0 : (steps > 64 ? 64 : steps), std::memory_order_relaxed); }
+// (override_fused_s2_steps, csrc/fsr1_overrides.h: 0 in the product library; libfsr1_hip_test.so can force a number of steps per run —
+//  any number gives the same image, tests/test_gpu_parity.py::test_fused_exact_2x_run_steps)
 int fused_s2_run_steps(int width, int height, int frames, int cus, int wgs_per_cu, bool overlapped) {
-  if (const int forced = g_fs2_forced_steps.load(std::memory_order_relaxed); forced > 0) return forced;
+  if (const int forced = override_fused_s2_steps(); forced > 0) return forced;
   const long long tiles1 = (long long)((width + kFs2OutW - 1) / kFs2OutW) * ((height + kFs2Step - 3) / (kFs2Step - 2)) * frames;
   // (cus: the device's compute units — 256 on MI355X, where the rule was measured; wgs_per_cu: what the kernel's LDS admits, 7 for
   //  the F kernel, 5 for the packed-fp16 one)
@@ -61,11 +60,9 @@ int fused_s2_run_steps(int width, int height, int frames, int cus, int wgs_per_c
 // makes walking lose on one frame (profiles/ab_r04/r4c1_fused_trace.log: a launch's first residency runs its steps in lock-step and
 // its tail is as long as a run).  Three workgroups of eight waves per CU (38.7 KB of LDS each).  Small frames keep the 256-thread
 // tile: twice as many workgroups to spread over the CUs.
-static std::atomic<int> g_fs2_forced_tall{-1};  // test hook (fsr1_debug_fused_tall_tiles): -1 = the rule, 0 = never, 1 = whenever the launch is one-step
-void fused_s2_force_tall(int mode) { g_fs2_forced_tall.store(mode < 0 ? -1 : (mode ? 1 : 0), std::memory_order_relaxed); }
 bool fused_s2_tall_tiles(int width, int height, int frames, int steps, int cus, int fmt) {
   if (steps != 1 || fmt == FSR1_FORMAT_RGBA32F) return false;
-  if (const int forced = g_fs2_forced_tall.load(std::memory_order_relaxed); forced >= 0) return forced != 0;
+  if (const int forced = override_fused_s2_tall(); forced >= 0) return forced != 0;  // (-1 in the product library)
   const long long tall = (long long)((width + kFs2OutW - 1) / kFs2OutW) * ((height + 29) / 30) * frames;
   return tall >= 4ll * 3 * (cus > 0 ? cus : 256);  // at least four residencies of tall tiles
 }

@@ -10,9 +10,12 @@
  *            (sample/src/DX12/FSR_Filter.cpp:101-141); fsr1_upscale is Upscale() itself.
  *
  * Plain pointers and sizes only; device memory is caller-owned; every dispatch is asynchronous on
- * the HIP stream passed as an opaque void* (NULL = the default stream); no hidden global state
- * except a per-thread last-error string.  All functions returning int return 0 on success and a
- * negative fsr1_status on failure.
+ * the HIP stream passed as an opaque void* (NULL = the default stream).  The library holds no
+ * process-wide state that a call can set or that changes what a later call does: besides the per-thread
+ * last-error string there are only idempotent per-device caches of device attributes (the CU count and
+ * the dynamic-LDS limit already granted to a kernel).  The switches that force a launch shape for tests
+ * live in a separate library, libfsr1_hip_test.so (include/fsr1_hip_test.h), not in this one.
+ * All functions returning int return 0 on success and a negative fsr1_status on failure.
  */
 #ifndef FSR1_HIP_H
 #define FSR1_HIP_H
@@ -287,15 +290,33 @@ int fsr1_upscale_plan(const fsr1_image* in, int32_t have_intermediary, const fsr
  * 64.0, fused launch 63.0 / 54.7 / 54.4 / 59.0, 1440p -> 4K 79.8 / 71.3 / 70.9 / 74.6, 540p -> 1080p two dispatches 28.7 / 20.4 / 17.1 /
  * 22.0: N = 3 is never worse than 2 and what bench.py and the runner default to; 4 loses.  The reference's sample has one graphics queue and
  * no counterpart; this is what its async-compute note (FSR_Filter.cpp:101 ff. run inside the frame's command list) leaves to
- * the engine.  The images of submissions that may overlap (the last N) must not alias; a pipeline is driven by one host thread
- * at a time.  fork / join order the pipeline's streams against a stream of the caller's.
+ * the engine.
+ *
+ * Ordering and aliasing — the rule the code enforces, no more: HIP streams are ordered only within themselves.  Submission i runs
+ * on slot i mod N and is ordered after submission i - N, i - 2N, ... (the same slot) and after nothing else: a long submission on
+ * one slot can still be running while several later ones on the other slots have come and gone.  Therefore
+ *   - an image (input, output) may be reused by a LATER submission only if that submission lands on the SAME slot
+ *     (fsr1_pipeline_next_slot tells which slot the next submission takes), or after fsr1_pipeline_join / _synchronize;
+ *   - a ring of frame buffers that is a multiple of N long, walked in submission order, satisfies this by construction
+ *     (bench.py and runner/fsr1_runner.c round their rings up to a multiple of N for that reason);
+ *   - "the last N submissions" is NOT a safe window in general (N = 2: submission 4 may start while a long submission 1 still runs).
+ * A pipeline is driven by one host thread at a time.  fork / join order the pipeline's streams against a stream of the caller's.
  * ---------------------------------------------------------------------------------------------- */
 typedef struct fsr1_pipeline fsr1_pipeline; /* opaque */
 int fsr1_pipeline_create(fsr1_pipeline** pipeline, int32_t streams /* 1 .. 8 */);
-/* fsr1_upscale_ex for one frame (or batch) on the pipeline's next stream, with that stream's own intermediary (allocated and
- * grown on demand; params->fused = 2 decides as if an intermediary was supplied).  Asynchronous. */
+/* fsr1_upscale_ex for one frame (or batch) on the pipeline's next stream, with that stream's own intermediary
+ * (params->fused = 2 decides as if an intermediary was supplied).  Asynchronous: when the slot's intermediary is too small it is
+ * re-allocated in stream order on the slot's own stream (hipFreeAsync / hipMallocAsync — no host block, no device-wide
+ * synchronisation).  While the stream is being captured into a hipGraph a growth is refused with FSR1_ERR_INVALID_ARGUMENT and a
+ * message naming the size to reserve: call fsr1_pipeline_reserve before the capture. */
 int fsr1_pipeline_upscale(fsr1_pipeline* pipeline, const fsr1_image* in, const fsr1_image* out, const fsr1_params* params,
                           const fsr1_color_stages* stages);
+/* Pre-sizes every slot's intermediary to at least bytes_per_stream (= out width x height x bytes per pixel x frames of the largest
+ * frame the two-dispatch pipeline will see), so that no later submission allocates: what a host does once before capturing frames
+ * into a hipGraph, or to keep allocation out of its frame loop.  Intermediaries never shrink. */
+int fsr1_pipeline_reserve(fsr1_pipeline* pipeline, size_t bytes_per_stream);
+/* The slot (0 .. streams - 1) the next fsr1_pipeline_upscale will run on; -1 for a null pipeline.  See the aliasing rule above. */
+int fsr1_pipeline_next_slot(const fsr1_pipeline* pipeline);
 /* Work submitted to the pipeline after fork() starts only after what `stream` holds now (e.g. the producer of the inputs). */
 int fsr1_pipeline_fork(fsr1_pipeline* pipeline, void* stream);
 /* Work submitted to `stream` after join() starts only after everything the pipeline holds now (e.g. a consumer of the outputs). */
@@ -321,15 +342,10 @@ int fsr1_device_count(void);
  * that the reference's ARcpH1/ARcpH2/ARcpF1 (ffx_a.h:1005, GLSL `1.0/x`) are pinned to. */
 int fsr1_selftest(uint32_t* failures);
 
-/* Test hook (process-wide, not part of the reference's surface): force the number of 16-row steps the workgroups of the exact-2x
- * fused launch walk down their columns (fsr1_fused_s2.hip), clamped to 0 .. 64; 0 restores the host's rule.  Every value gives
- * the same image, bit for bit — which is what tests/test_gpu_parity.py::test_fused_exact_2x_run_steps uses it to show. */
-void fsr1_debug_fused_run_steps(int32_t steps);
-/* ... and the tile shape of its one-step launches: -1 = the host's rule (the 62 x 30 tile of a 512-thread workgroup for frames that
- * fill the chip, the 62 x 14 tile of a 256-thread one otherwise), 0 = never the tall tile, 1 = always.  Same image either way. */
-void fsr1_debug_fused_tall_tiles(int32_t mode);
-/* ... and of exact-2x EASU launches (F arithmetic): 64 x 32 tiles for large or overlapped launches, 64 x 16 otherwise; -1 / 0 / 1 as above. */
-void fsr1_debug_easu_tall_tiles(int32_t mode);
+/* The hash of the kernel sources this binary was built from (csrc/ + include/, first 16 hex digits of a SHA-256), baked in at build
+ * time.  A host that also has the source tree compares it with the tree's hash (fidelityfx-fsr_amd/_lib.py:source_hash(); bench.py
+ * prints both and says "binary_matches_sources": false when a stale prebuilt binary is running). */
+const char* fsr1_build_id(void);
 
 /* HIP-event stopwatch on a caller stream (used by the bench so that kernel time is measured on the
  * very stream the kernels run on).  Handles are opaque. */

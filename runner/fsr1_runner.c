@@ -247,6 +247,9 @@ static int worker_body(worker_t* w) {
     if (ring < 2) ring = 2;
   }
   if (o->streams > 1 && ring < o->streams + 1) ring = o->streams + 1;  /* the outputs of steps that may be in flight together must not alias */
+  /* ... and a multiple of the stream count: step i runs on slot i mod S, so set i mod ring is then only ever reused by a submission on
+   * the same slot — the one reuse a pipeline orders (include/fsr1_hip.h, "Ordering and aliasing") */
+  if (o->streams > 1) ring = (ring + o->streams - 1) / o->streams * o->streams;
   w->ring = ring;
   if (nf > 0) {
     HIP_OK(w, hipMalloc(&w->d_in, in_frame * nf * ring));

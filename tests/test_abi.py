@@ -10,8 +10,8 @@ import pytest
 from conftest import ROOT
 
 
-def header_symbols():
-    text = open(os.path.join(ROOT, "include", "fsr1_hip.h")).read()
+def header_symbols(header="fsr1_hip.h"):
+    text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     names = re.findall(r"^\s*(?:const\s+)?(?:void|int|uint32_t|char\s*\*|const char\s*\*)\s*\*?\s*([A-Za-z_][A-Za-z0-9_]*)\s*\(", text, flags=re.M)
     return sorted(set(names))
@@ -25,6 +25,38 @@ def test_header_symbols_are_exported(fsr):
     for s in syms:
         assert hasattr(lib, s), "include/fsr1_hip.h declares %s but libfsr1_hip.so does not export it" % s
     assert set(syms) == set(fsr._lib.SYMBOLS), "python prototypes and header disagree"
+
+
+def test_test_hooks_live_in_the_test_library_only(fsr):
+    """include/fsr1_hip_test.h's process-wide launch-shape switches are exported by libfsr1_hip_test.so and NOT by the product
+    library, whose header promises no such state; the test library otherwise exports the whole product ABI."""
+    prod = ctypes.CDLL(fsr._lib.LIB_PATH)
+    test = ctypes.CDLL(fsr._lib.TEST_LIB_PATH)
+    hooks = header_symbols("fsr1_hip_test.h")
+    assert set(hooks) == set(fsr._lib.TEST_SYMBOLS) and len(hooks) == 3
+    for s in hooks:
+        assert hasattr(test, s), "libfsr1_hip_test.so does not export %s" % s
+        assert not hasattr(prod, s), "the product library exports the test hook %s" % s
+    for s in header_symbols():
+        assert hasattr(test, s), "libfsr1_hip_test.so lacks %s" % s
+    blob = open(fsr._lib.LIB_PATH, "rb").read()
+    assert b"fsr1_debug_" not in blob
+
+
+def test_build_id_is_the_hash_of_the_sources(fsr):
+    """fsr1_build_id() — baked into the binary by csrc/Makefile — equals _lib.source_hash() of the tree it was built from: the bench
+    line's way to notice a stale prebuilt library running beside newer sources."""
+    assert fsr._lib.build_id() == fsr._lib.source_hash()
+    test = fsr._lib.load_test()
+    assert test.fsr1_build_id().decode() == fsr._lib.source_hash()
+    assert re.fullmatch(r"[0-9a-f]{16}", fsr._lib.build_id())
+
+
+def test_pipeline_argument_validation(fsr):
+    """fsr1_pipeline_reserve / _next_slot reject a null pipeline before touching the device (no GPU needed)."""
+    lib = fsr.load()
+    assert lib.fsr1_pipeline_reserve(None, 1 << 20) == -1 and b"null" in lib.fsr1_last_error()
+    assert lib.fsr1_pipeline_next_slot(None) == -1
 
 
 def test_version(fsr):

@@ -610,8 +610,8 @@ def test_fused_exact_2x_run_steps(fsr, shape, steps):
         two = torch.zeros_like(mid)
         fsr.easu(src, mid, flags=flags & fsr.FLAG_MATH_EXACT)
         fsr.rcas(mid, two, sharpness=0.3, flags=flags)
-        fsr.load().fsr1_debug_fused_run_steps(steps)
-        try:
+        with fsr._lib.test_hooks() as hooks:  # libfsr1_hip_test.so (include/fsr1_hip_test.h); the two dispatches above ran in the product library
+            hooks.fsr1_debug_fused_run_steps(steps)
             big_out = torch.full((n, oh + 1, ow + 5, 4), 7, dtype=torch.float16, device="cuda")
             dst = big_out[:, :oh, :ow]
             fsr.easu_rcas_fused(src, dst, sharpness=0.3, flags=flags)
@@ -624,8 +624,6 @@ def test_fused_exact_2x_run_steps(fsr, shape, steps):
                 if y1 > y0:
                     fsr.upscale_band(src[0], band[y0:y1], (ow, oh), (y0, y1), sharpness=0.3, flags=flags, fused=True)
             assert torch.equal(band.view(torch.int16), two[0].view(torch.int16)), "bands at steps %d != two dispatches (flags %d)" % (steps, flags)
-        finally:
-            fsr.load().fsr1_debug_fused_run_steps(0)
 
 
 @pytest.mark.parametrize("shape", [(97, 160), (31, 75), (64, 40), (70, 9), (1, 1), (200, 31)], ids=lambda s: "%dx%d" % s)
@@ -637,9 +635,8 @@ def test_fused_exact_2x_tall_tiles(fsr, shape):
     ow, oh = 2 * iw, 2 * ih
     n = 2
     src = dev(np.stack([frames.synthetic_frame(iw, ih, k=60 + f, dtype=np.float16) for f in range(n)]))
-    lib = fsr.load()
-    lib.fsr1_debug_fused_tall_tiles(1)
-    try:
+    with fsr._lib.test_hooks() as lib:  # libfsr1_hip_test.so (include/fsr1_hip_test.h)
+        lib.fsr1_debug_fused_tall_tiles(1)
         for flags in (0, fsr.FLAG_MATH_EXACT | fsr.FLAG_RCAS_DENOISE, fsr.FLAG_RCAS_PASSTHROUGH_ALPHA | fsr.FLAG_HDR_SQUARE):
             mid = torch.zeros(n, oh, ow, 4, dtype=torch.float16, device="cuda")
             two = torch.zeros_like(mid)
@@ -666,8 +663,6 @@ def test_fused_exact_2x_tall_tiles(fsr, shape):
         fsr.rcas(mid8, two8, sharpness=0.3)
         fsr.easu_rcas_fused(src8, one8, sharpness=0.3)
         assert torch.equal(one8, two8)
-    finally:
-        lib.fsr1_debug_fused_tall_tiles(-1)
 
 
 def test_selftest_binary32_rcp_ieee_over_all_operands(fsr):
@@ -689,23 +684,20 @@ def test_easu_exact_2x_tall_tiles(fsr, shape):
     iw, ih = shape
     ow, oh = 2 * iw, 2 * ih
     n = 2
-    lib = fsr.load()
     src16 = dev(np.stack([frames.synthetic_frame(iw, ih, k=80 + f, dtype=np.float16) for f in range(n)]))
     for src in (src16, src16.float(), (src16.float().clamp(0, 1) * 255 + 0.5).to(torch.uint8)):
         for flags in (0, fsr.FLAG_MATH_EXACT, fsr.FLAG_HDR_SQUARE | fsr.FLAG_OUTPUT_STREAMING):
-            lib.fsr1_debug_easu_tall_tiles(0)
-            want = torch.zeros(n, oh, ow, 4, dtype=src.dtype, device="cuda")
-            fsr.easu(src, want, flags=flags)
-            gen = torch.zeros_like(want)
-            fsr.easu(src, gen, flags=flags | fsr.FLAG_NO_FAST_PATHS)
-            lib.fsr1_debug_easu_tall_tiles(1)
-            try:
+            with fsr._lib.test_hooks() as lib:  # libfsr1_hip_test.so (include/fsr1_hip_test.h)
+                lib.fsr1_debug_easu_tall_tiles(0)
+                want = torch.zeros(n, oh, ow, 4, dtype=src.dtype, device="cuda")
+                fsr.easu(src, want, flags=flags)
+                gen = torch.zeros_like(want)
+                fsr.easu(src, gen, flags=flags | fsr.FLAG_NO_FAST_PATHS)
+                lib.fsr1_debug_easu_tall_tiles(1)
                 big = torch.full((n, oh + 1, ow + 5, 4), 7, dtype=src.dtype, device="cuda")
                 got = big[:, :oh, :ow]
                 fsr.easu(src, got, flags=flags)
                 torch.cuda.synchronize()
-            finally:
-                lib.fsr1_debug_easu_tall_tiles(-1)
             assert bool((big[:, oh:] == 7).all()) and bool((big[:, :, ow:] == 7).all()), "wrote outside the output view"
             assert torch.equal(got, want) and torch.equal(gen, want), (str(src.dtype), flags)
             hint = torch.zeros_like(want)

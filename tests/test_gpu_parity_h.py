@@ -242,8 +242,8 @@ def test_fused_h_exact_2x_walk_equals_two_pass_h(fsr, shape, steps):
     n = 2
     h = fsr.FLAG_MATH_PACKED_FP16
     src = dev(np.stack([frames.synthetic_frame(iw, ih, k=50 + f, dtype=np.float16) for f in range(n)]))
-    fsr.load().fsr1_debug_fused_run_steps(steps)
-    try:
+    with fsr._lib.test_hooks() as hooks:  # libfsr1_hip_test.so (include/fsr1_hip_test.h)
+        hooks.fsr1_debug_fused_run_steps(steps)
         for opts in (0, fsr.FLAG_RCAS_DENOISE | fsr.FLAG_RCAS_PASSTHROUGH_ALPHA, fsr.FLAG_HDR_SQUARE):
             mid = torch.zeros(n, oh, ow, 4, dtype=torch.float16, device="cuda")
             two = torch.zeros_like(mid)
@@ -258,8 +258,6 @@ def test_fused_h_exact_2x_walk_equals_two_pass_h(fsr, shape, steps):
             gen = torch.zeros_like(two)
             fsr.easu_rcas_fused(src, gen, sharpness=0.3, flags=h | opts | fsr.FLAG_NO_FAST_PATHS)
             assert torch.equal(gen.view(torch.int16), two.view(torch.int16)), "generic fused H != two H dispatches (opts %d)" % opts
-    finally:
-        fsr.load().fsr1_debug_fused_run_steps(0)
 
 
 def test_fused_h_batch_with_pitches(fsr):

@@ -142,10 +142,101 @@ def test_pipeline_is_graph_capturable(fsr):
     pipe.close()
 
 
+def test_graph_capture_on_a_cold_pipeline_after_reserve(fsr):
+    """fsr1_pipeline_reserve sizes every stream's intermediary up front, so a pipeline that has never run a frame can be captured
+    into a graph; WITHOUT the reserve the capture's first submission is refused with a message that names the size (not a broken
+    capture), and the pipeline stays usable."""
+    iw, ih, ow, oh = 240, 135, 480, 270
+    srcs = [dev(frames.synthetic_frame(iw, ih, k=20 + k, dtype=np.float16)) for k in range(6)]
+    want = [alone(fsr, s, ow, oh, False, 0) for s in srcs]
+    outs = [torch.zeros(oh, ow, 4, dtype=torch.float16, device="cuda") for _ in srcs]
+    torch.cuda.synchronize()
+    # (a) cold pipeline, no reserve: refused inside the capture
+    cold = fsr.Pipeline(2)
+    cap = torch.cuda.Stream()
+    g0 = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(cap):
+        with torch.cuda.graph(g0, stream=cap):
+            cold.fork(cap)
+            with pytest.raises(fsr.Fsr1Error, match="fsr1_pipeline_reserve"):
+                cold.upscale(srcs[0], outs[0], fused=0)
+            cold.upscale(srcs[0], outs[0], fused=1)  # the fused launch needs no intermediary: capturable as is
+            cold.join(cap)
+    g0.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0].view(torch.int16), want[0].view(torch.int16))
+    del g0
+    cold.close()
+    # (b) cold pipeline after reserve: captures and replays
+    outs[0].zero_()
+    pipe = fsr.Pipeline(3)
+    pipe.reserve(ow * oh * 8)
+    assert pipe.next_slot() == 0
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(cap):
+        with torch.cuda.graph(g, stream=cap):
+            pipe.fork(cap)
+            for s, o in zip(srcs, outs):
+                pipe.upscale(s, o, fused=0)
+            pipe.join(cap)
+    for _ in range(2):
+        g.replay()
+    torch.cuda.synchronize()
+    for k in range(6):
+        assert torch.equal(outs[k].view(torch.int16), want[k].view(torch.int16)), k
+    del g
+    pipe.close()
+
+
+def test_intermediary_grows_in_stream_order_without_blocking(fsr):
+    """Frame sizes that grow from submission to submission: every slot's intermediary is re-allocated on its own stream (hipFreeAsync /
+    hipMallocAsync) while earlier frames of the other slots are still in flight; every frame equals the frame upscaled alone, and
+    next_slot() walks 0, 1, 2, 0, ..."""
+    shapes = [(120, 68, 240, 136), (240, 135, 480, 270), (480, 270, 960, 540), (960, 540, 1920, 1080), (240, 135, 480, 270), (1280, 720, 2560, 1440)] * 2
+    pipe = fsr.Pipeline(3)
+    srcs = [dev(frames.synthetic_frame(iw, ih, k=11 + k, dtype=np.float16)) for k, (iw, ih, _, _) in enumerate(shapes)]
+    outs = [torch.full((oh, ow, 4), -2.0, dtype=torch.float16, device="cuda") for (_, _, ow, oh) in shapes]
+    for k, (s, o) in enumerate(zip(srcs, outs)):
+        assert pipe.next_slot() == k % 3
+        pipe.upscale(s, o, fused=0)
+    pipe.synchronize()
+    for k, (s, o, (iw, ih, ow, oh)) in enumerate(zip(srcs, outs, shapes)):
+        assert torch.equal(o.view(torch.int16), alone(fsr, s, ow, oh, False, 0).view(torch.int16)), k
+    pipe.close()
+
+
+def test_managed_pipeline_orders_itself_after_the_current_torch_stream(fsr):
+    """Pipeline(managed=True), the default: no fork() — each submission's stream waits for what the current torch stream holds (the
+    producer of the input), and the tensors stay referenced while in flight even if the caller drops them."""
+    iw, ih, ow, oh = 480, 270, 960, 540
+    base = dev(frames.synthetic_frame(iw, ih, k=9, dtype=np.float16))
+    want = [alone(fsr, torch.roll(base, shifts=(k, 2 * k), dims=(0, 1)).contiguous(), ow, oh, False, 0) for k in range(6)]
+    torch.cuda.synchronize()
+    pipe = fsr.Pipeline(3)
+    side = torch.cuda.Stream()
+    outs = []
+    with torch.cuda.stream(side):
+        for k in range(6):
+            big = torch.zeros(64, 1024, 1024, device="cuda")  # work in front of the producer: an unordered reader would be early
+            big.add_(1.0)
+            src = torch.roll(base, shifts=(k, 2 * k), dims=(0, 1)).contiguous()
+            out = torch.zeros(oh, ow, 4, dtype=torch.float16, device="cuda")
+            pipe.upscale(src, out, fused=0)
+            outs.append(out)
+            del src, big  # the allocator may not reuse src's memory while the pipeline still reads it
+        pipe.join(side)
+        sums = [o.float().sum() for o in outs]
+    side.synchronize()
+    for k in range(6):
+        assert torch.equal(outs[k].view(torch.int16), want[k].view(torch.int16)), k
+        assert float(sums[k]) == float(want[k].float().sum())
+    pipe.close()
+
+
 def test_pipeline_fork_and_join_order_against_the_callers_stream(fsr):
     """Inputs produced on the caller's stream right before fork(), outputs consumed on it right after join(): no host synchronisation."""
     iw, ih, ow, oh = 480, 270, 960, 540
-    pipe = fsr.Pipeline(2)
+    pipe = fsr.Pipeline(2, managed=False)  # the bare C ABI: ordering comes from fork / join alone
     base = dev(frames.synthetic_frame(iw, ih, k=3, dtype=np.float16))
     want = [alone(fsr, torch.roll(base, shifts=(k, 2 * k), dims=(0, 1)).contiguous(), ow, oh, False, 0) for k in range(6)]
     torch.cuda.synchronize()

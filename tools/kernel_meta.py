@@ -15,17 +15,36 @@ import subprocess
 import sys
 import tempfile
 
-LLVM = "/opt/rocm/lib/llvm/bin"
+def _llvm_bin():
+    """llvm-objdump / llvm-readelf of the ROCm tree: $ROCM_PATH, hipconfig --rocmpath, /opt/rocm, then PATH."""
+    roots = [os.environ.get("ROCM_PATH"), "/opt/rocm"]
+    try:
+        roots.insert(1, subprocess.run(["hipconfig", "--rocmpath"], capture_output=True, text=True, timeout=20).stdout.strip())
+    except (OSError, subprocess.SubprocessError):
+        pass
+    for r in roots:
+        if r and os.path.exists(os.path.join(r, "lib", "llvm", "bin", "llvm-objdump")):
+            return os.path.join(r, "lib", "llvm", "bin")
+    found = shutil.which("llvm-objdump")
+    if found:
+        return os.path.dirname(found)
+    raise FileNotFoundError("llvm-objdump not found under $ROCM_PATH, `hipconfig --rocmpath`, /opt/rocm or PATH")
+
+
+LLVM = None
 
 
 def kernel_meta(lib):
+    global LLVM
+    if LLVM is None:
+        LLVM = _llvm_bin()
     out = {}
     with tempfile.TemporaryDirectory() as tmp:
         copy = os.path.join(tmp, os.path.basename(lib))
         shutil.copy(lib, copy)
         subprocess.run([os.path.join(LLVM, "llvm-objdump"), "--offloading", copy], check=True, capture_output=True)
         for f in sorted(os.listdir(tmp)):
-            if "gfx950" not in f:
+            if "gfx9" not in f:  # the code objects llvm-objdump --offloading extracts are named after their architecture (gfx950 here)
                 continue
             notes = subprocess.run([os.path.join(LLVM, "llvm-readelf"), "--notes", os.path.join(tmp, f)], capture_output=True, text=True).stdout
             for blk in notes.split("- .agpr_count")[1:]:
