@@ -587,17 +587,22 @@ def main():
         return t
 
     tele = Telemetry(torch, dev_index)
-    tele.begin("headline")  # ramp + warm-up + the headline's timed regions: the same pipelined load throughout
     # Device clock ramp (not part of W): an idle MI355X sits at ~100 MHz and needs a few milliseconds of load
     # to reach its working clocks; EASU then runs AT the 1400 W package power cap (sclk ~2.1 of 2.4 GHz), so the
     # steady state is what a frame stream sees.  ~0.2 s of the same steps, untimed.
     t_ramp = time.perf_counter()
     i = 0
+    ramp_half = False
     while time.perf_counter() - t_ramp < 0.2:
         step(i)
         i += 1
         if i % 64 == 0:
             torch.cuda.synchronize()
+        if not ramp_half and time.perf_counter() - t_ramp >= 0.1:
+            # telemetry of the headline: the second half of the ramp (clocks and power have settled), the warm-up, the timed regions and
+            # the steady-state run — the same pipelined load throughout (a K = 20 region alone is 1.3 ms: less than one 2 ms sample)
+            ramp_half = True
+            tele.begin("headline")
     for i in range(args.warmup):
         step(i)
     fence()
@@ -633,7 +638,6 @@ def main():
         regions, own_regions = timed(lambda i: g.replay(), args.steps // args.graph)
     else:
         regions, own_regions = timed(step, args.steps, first=args.warmup)
-    tele.end("headline")
     seconds = median(regions)
 
     def steady(fn, k, stream_of_last):
@@ -667,9 +671,8 @@ def main():
 
     steady_regions = None
     if not args.no_steady and args.graph == 0:
-        tele.begin("steady")
         steady_regions = steady(step, args.steps, last_pipe_stream if pipe is not None else (lambda: None))
-        tele.end("steady")
+    tele.end("headline")
 
     # the same K steps on ONE in-order stream (the method of rounds 1-3): the per-kernel stopwatch below is taken that way, and the
     # line's self-consistency check compares the kernels with THIS step (overlapped steps are shorter than the kernels they contain)
@@ -928,12 +931,12 @@ def main():
                        "pipeline": args.pipeline, "storage": args.storage, "color_stages": args.stages, "hip_graph_steps": args.graph, "rcas_sharpness_stops": 0.25,
                        "parallelism": "independent frames per GPU, counters-only collective"},
             "per_rank_seconds": [round(t, 6) for t in per_rank_seconds],
-            # shader clock (median MHz) and package power (mean W) every rank's GPU showed during its headline regions (ramp + warm-up +
-            # timed regions), read from the amdgpu driver's sysfs files by a host thread; null where a box does not expose them
+            # shader clock (median MHz) and package power (mean W) every rank's GPU showed under the headline's load (second half of the
+            # ramp, warm-up, timed regions, steady-state run), read from the amdgpu driver's sysfs files by a host thread; null where a
+            # box does not expose them
             "per_rank_mhz": per_rank_mhz, "per_rank_watts": per_rank_watts,
             "telemetry": {"source": tele.source, "samples_rank0": head_n, "period_ms": tele.period * 1e3,
                           "one_stream": dict(zip(("mhz", "watts", "samples"), tele.summary("one_stream"))),
-                          "steady": dict(zip(("mhz", "watts", "samples"), tele.summary("steady"))),
                           "latency": dict(zip(("mhz", "watts", "samples"), tele.summary("latency")))},
             "roofline": roof(dominant),
             "kernels": {k: roof(k) for k in kern},

@@ -100,40 +100,75 @@ __device__ __forceinline__ void easu_stage_footprint(const EasuLds& l, const Ima
                                                      int fw_rt, int fh_rt, int tid, const ColorArgs* color = nullptr) {
   typedef typename Pixel<FMT>::T texel_t;
   const int fw = FW ? FW : fw_rt, fh = FH ? FH : fh_rt;
-  const int n = fw * fh - 1;
-  const float inv_fw = 1.0f / (float)fw;
-  auto row_of = [&](int i) { return FW ? i / FW : (int)(((float)i + 0.5f) * inv_fw); };  // exact for the few thousand texels of a footprint
-  // ---- phase 1: HBM -> LDS, one coalesced pass, fp32 once per input texel ----
-  const int gy0 = min(max(fy0, 0), in.height - 1);  // first row the footprint reads
-  const char* const base = in_frame + (long long)gy0 * in.pitch;
-  const uint32_t pitch = (uint32_t)in.pitch;
   constexpr int kRow = PITCH ? 2 * PITCH : 0;  // LDS row pitch (records) of the interleaved layout
-  auto stage = [&](int i, int ly, uint32_t off) {
-    const texel_t px = *reinterpret_cast<const texel_t*>(base + (size_t)off);
+  auto texel_record = [&](const texel_t& px) {
     float4_t c = Pixel<FMT>::load(px);
     if constexpr (PRE) c = color_prologue<EXACT>(*color, c);
     // :363-366  luma*2 = B*0.5 + (R*0.5 + G); the products by 0.5 are exact, so fusing them is too
-    l.tex[PITCH ? ly * kRow + (i - ly * fw) : i] = float4_t{c.x, c.y, c.z, fmaf(c.z, 0.5f, fmaf(c.x, 0.5f, c.y))};
+    return float4_t{c.x, c.y, c.z, fmaf(c.z, 0.5f, fmaf(c.x, 0.5f, c.y))};
   };
-  if (fx0 >= 0 && fy0 >= 0 && fx0 + fw <= in.width && fy0 + fh <= in.height) {  // wave-uniform: nothing to clamp (all tiles but the image's border)
-    const uint32_t x_off = (uint32_t)fx0 * (uint32_t)sizeof(texel_t);
-    for (int i = tid; i < n; i += THREADS) {
-      const int ly = row_of(i);
-      stage(i, ly, (uint32_t)ly * pitch + (uint32_t)(i - ly * fw) * (uint32_t)sizeof(texel_t) + x_off);
+  // ---- phase 1: HBM -> LDS, one coalesced pass, fp32 once per input texel ----
+  if (PITCH || FW || fw <= 64) {
+    // Footprints up to 64 texels wide (every upscaling ratio; compile-time for the pitched and the exact-2x kernels): ONE LANE PER
+    // FOOTPRINT COLUMN, ONE WAVE PER FOOTPRINT ROW (round 5).  A row is then wave-uniform — its clamp and its 64-bit base address
+    // are scalar work, the column clamp is done once per lane, the LDS record of (row, lane) is a base register plus a scalar /
+    // immediate offset — and a wave issues the loads of ALL its rows before it converts the first: up to kU requests per lane in
+    // flight instead of one after the other.  The linear walk below spends 11 of its 19 VALU instructions per texel on index
+    // arithmetic and waits for every load before it issues the next.  Lanes beyond the footprint's width idle (a row is one
+    // wave-instruction either way).  Measured (profiles/ab_r05/r5c2_ab_stagerows.log, EASU us): 1440p -> 4K 53.8 -> 51.8-52.2,
+    // 2954x1662 -> 4K 59.4 -> 56.0, 1477x831 -> 1080p 18.9 -> 17.2, 8-frame 1440p -> 4K batch 406 -> 395.
+    static_assert(PITCH <= 64 && FW <= 64 && THREADS % 64 == 0, "one lane per footprint column");
+    constexpr int kWaves = THREADS / 64;
+    // rows per wave and trip: all of a compile-time footprint's, five otherwise (16-row tiles of any upscaling ratio have <= 20
+    // rows), but no more than 48 bytes of raw texels per lane (RGBA32F: three rows — the exact-2x kernels have no registers to spare)
+    constexpr int kWant = FH ? (FH + kWaves - 1) / kWaves : 5, kFit = 48 / (int)sizeof(texel_t);
+    constexpr int kU = kWant < kFit ? kWant : kFit;
+    const int rs = PITCH ? kRow : fw;                        // LDS records between footprint rows
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t xoff = (uint32_t)min(max(fx0 + lane, 0), in.width - 1) * (uint32_t)sizeof(texel_t);
+    float4_t* const rec = l.tex + lane;
+    if (lane < fw) {
+#pragma unroll 1
+      for (int ly0 = wave; ly0 < fh; ly0 += kWaves * kU) {
+        texel_t px[kU];
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+          const int ly = ly0 + kWaves * u;  // wave-uniform
+          if (ly < fh) {
+            const int gy = min(max(fy0 + ly, 0), in.height - 1);
+            px[u] = *reinterpret_cast<const texel_t*>(in_frame + (long long)gy * in.pitch + (size_t)xoff);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+          const int ly = ly0 + kWaves * u;
+          if (ly < fh) rec[ly * rs] = texel_record(px[u]);
+        }
+      }
     }
   } else {
+    // wider footprints (minification): the linear walk, 256 texels per pass
+    const int n = fw * fh - 1;
+    // (v_rcp_f32, 1 ulp, instead of the IEEE division's dozen instructions: (i + 0.5) / fw lies at least 0.5 / fw from an integer, the
+    //  product's error is below 1e-4 for a footprint's few thousand texels)
+    const float inv_fw = __builtin_amdgcn_rcpf((float)fw);
+    auto row_of = [&](int i) { return (int)(((float)i + 0.5f) * inv_fw); };
+    const int gy0 = min(max(fy0, 0), in.height - 1);  // first row the footprint reads
+    const char* const base = in_frame + (long long)gy0 * in.pitch;
+    const uint32_t pitch = (uint32_t)in.pitch;
     for (int i = tid; i < n; i += THREADS) {
       const int ly = row_of(i);
       const int gy = min(max(fy0 + ly, 0), in.height - 1);
       const int gx = min(max(fx0 + (i - ly * fw), 0), in.width - 1);
-      stage(i, ly, (uint32_t)(gy - gy0) * pitch + (uint32_t)gx * (uint32_t)sizeof(texel_t));
+      l.tex[i] = texel_record(*reinterpret_cast<const texel_t*>(base + (size_t)((uint32_t)(gy - gy0) * pitch + (uint32_t)gx * (uint32_t)sizeof(texel_t))));
     }
   }
   __syncthreads();
   // ---- phase 2: FsrEasuSetF's per-position terms, for the texels that are read as f/g/j/k of some pixel: columns
   //      1..fw-2, rows 1..fh-2 of the footprint (every neighbour of those lies inside it, so nothing is clamped). ----
   const int iw = fw - 2, m = iw * (fh - 2);
-  const float inv_iw = 1.0f / (float)iw;
+  const float inv_iw = __builtin_amdgcn_rcpf((float)iw);  // (1 ulp: see inv_fw above)
   const float* const lum = reinterpret_cast<const float*>(l.tex) + 3;  // luma of texel i at lum[4 * i]
   for (int j = tid; j < m; j += THREADS) {
     const int y = FW ? j / (FW - 2) : (int)(((float)j + 0.5f) * inv_iw);

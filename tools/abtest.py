@@ -25,14 +25,18 @@ def child(args):
     import bench
     fsr = importlib.import_module("fidelityfx-fsr_amd")
     lib = fsr.load()
-    # `lib%FSR1_FUSED_S2_STEPS=n` / `%FSR1_FUSED_S2_TALL=m` in --libs: the variant runs with the library's test hooks set (the library
-    # itself reads no tuning value from the environment)
-    if os.environ.get("FSR1_FUSED_S2_STEPS") and hasattr(lib, "fsr1_debug_fused_run_steps"):
-        lib.fsr1_debug_fused_run_steps(int(os.environ["FSR1_FUSED_S2_STEPS"]))
-    if os.environ.get("FSR1_FUSED_S2_TALL") and hasattr(lib, "fsr1_debug_fused_tall_tiles"):
-        lib.fsr1_debug_fused_tall_tiles(int(os.environ["FSR1_FUSED_S2_TALL"]))
-    if os.environ.get("FSR1_EASU_TALL") and hasattr(lib, "fsr1_debug_easu_tall_tiles"):
-        lib.fsr1_debug_easu_tall_tiles(int(os.environ["FSR1_EASU_TALL"]))
+    # `lib%FSR1_FUSED_S2_STEPS=n` / `%FSR1_FUSED_S2_TALL=m` / `%FSR1_EASU_TALL=m` in --libs: the variant runs in the TEST library
+    # (lib*_test.so, include/fsr1_hip_test.h) with its launch-shape hooks set; the product library has no such switches and reads no
+    # tuning value from the environment
+    if any(os.environ.get(k) for k in ("FSR1_FUSED_S2_STEPS", "FSR1_FUSED_S2_TALL", "FSR1_EASU_TALL")):
+        lib = fsr._lib.load_test()
+        fsr._lib._lib = lib  # every call of the package goes through the test library from here on
+        if os.environ.get("FSR1_FUSED_S2_STEPS"):
+            lib.fsr1_debug_fused_run_steps(int(os.environ["FSR1_FUSED_S2_STEPS"]))
+        if os.environ.get("FSR1_FUSED_S2_TALL"):
+            lib.fsr1_debug_fused_tall_tiles(int(os.environ["FSR1_FUSED_S2_TALL"]))
+        if os.environ.get("FSR1_EASU_TALL"):
+            lib.fsr1_debug_easu_tall_tiles(int(os.environ["FSR1_EASU_TALL"]))
     dev = torch.device("cuda", 0)
     flags = {"f": 0, "exact": fsr.FLAG_MATH_EXACT, "h": fsr.FLAG_MATH_PACKED_FP16}[args.math]
     if args.no_fast_paths:

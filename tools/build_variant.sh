@@ -6,7 +6,7 @@ ROOT=$(cd "$(dirname "$0")/.." && pwd)
 NAME=$1; EXTRA=$2; shift; shift || true
 B=/tmp/fsr1_variant_$NAME
 rm -rf "$B"; mkdir -p "$B/pkg/csrc" "$B/include" "$ROOT/variants"
-cp "$ROOT"/fidelityfx-fsr_amd/csrc/*.hip "$ROOT"/fidelityfx-fsr_amd/csrc/*.h "$ROOT"/fidelityfx-fsr_amd/csrc/*.c "$ROOT"/fidelityfx-fsr_amd/csrc/Makefile "$B/pkg/csrc/"
+cp "$ROOT"/fidelityfx-fsr_amd/csrc/*.hip "$ROOT"/fidelityfx-fsr_amd/csrc/*.h "$ROOT"/fidelityfx-fsr_amd/csrc/*.c "$ROOT"/fidelityfx-fsr_amd/csrc/*.cpp "$ROOT"/fidelityfx-fsr_amd/csrc/Makefile "$B/pkg/csrc/"
 cp "$ROOT"/include/*.h "$ROOT"/include/*.hpp "$B/include/"
 for P in "$@"; do (cd "$B" && sed -e "s#fidelityfx-fsr_amd/csrc/#pkg/csrc/#g" "$(cd "$ROOT" && realpath "$P")" | patch -p1 -s) || { echo "patch $P failed"; exit 1; }; done
 make -C "$B/pkg/csrc" -j8 EXTRA="$EXTRA" LIB="$ROOT/variants/libfsr1_$NAME.so" > "$B/build.log" 2>&1 || { tail -5 "$B/build.log"; exit 1; }
