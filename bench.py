@@ -53,6 +53,8 @@ WORKLOADS = {
     "1440p_to_4k_x8": (2560, 1440, 3840, 2160, 8),       # configs[2]: 64 frames over 8 GPUs
     "4k_to_8k_x16": (3840, 2160, 7680, 4320, 16),        # configs[4]: 128 frames over 8 GPUs
     "4k_to_8k": (3840, 2160, 7680, 4320, 1),             # one 8K frame
+    "4k_to_8k_x4": (3840, 2160, 7680, 4320, 4),          # (sizes between one 8K frame and configs[4]'s shard: where `auto` switches for packed fp16)
+    "4k_to_8k_x8": (3840, 2160, 7680, 4320, 8),
     "1080p_to_4k_x2": (1920, 1080, 3840, 2160, 2),       # two / four / eight 4K frames per launch (the exact-2x shape as small batches)
     "1080p_to_4k_x4": (1920, 1080, 3840, 2160, 4),
     "1080p_to_4k_x8": (1920, 1080, 3840, 2160, 8),

@@ -14,6 +14,8 @@
 namespace fsr1 {
 hipError_t easu_launch(const EasuArgs& a, int fmt, bool exact, bool s2, bool tall, hipStream_t stream);
 bool easu_s2_tall_tiles(int width, int height, int frames, bool overlapped, int cus);
+bool easu_generic_tall_tiles(int width, int height, int frames, int cus, size_t lds_tall);
+int easu_lds_pitch(int fp_w, bool exact, bool color);
 size_t easu_lds_bytes(int fmt, int fp_w, int fp_h);
 hipError_t rcas_launch(const RcasArgs& a, int fmt, bool exact, hipStream_t stream);
 void rcas_geometry(int width, int height, int frames, bool overlapped, int* tiles_x, int* tiles_y, int* rows);
@@ -275,6 +277,13 @@ static bool auto_takes_fused(const fsr1_image* in, bool have_intermediary, const
     if ((packed ? fused_h_lds_bytes(fp_w, fp_h) : fused_lds_bytes(in->format, fp_w, fp_h)) > 160 * 1024) return false;
   }
   const long long out_pixels = (long long)out->width * (long long)out->height * (long long)out->frames;
+  // Packed fp16 at exactly 2x has a quad-form fused launch of its own (fsr1_fused_s2_h.hip, round 4) that walks longer runs the larger
+  // the launch is.  Measured against the two H dispatches (round 5, profiles/ab_r05/r5c4_ab_h_auto.log, r5c5_ab_h_auto2.log, us per
+  // launch, two dispatches / fused): 540p -> 1080p 34.8 / 29.8, 720p -> 1440p 50.9 / 47.0, one 4K frame 93.7 / 95.6, four 4K frames or
+  // one 8K frame 348 / 359, eight 4K frames 708 / 685, four 8K frames 1347 / 1345, eight 2690 / 2640, sixteen 5450 / 5240: the fused
+  // launch up to 4 Mpixel of output and from 60 Mpixel up, the two dispatches between.
+  const bool packed_2x = con_2x && packed && !(math & FSR1_FLAG_NO_FAST_PATHS) && !have_stages;
+  if (packed_2x && (out_pixels <= 4000000ll || out_pixels >= 60000000ll)) return true;
   return quad_form || out_pixels <= 3000000ll;
 }
 
@@ -358,8 +367,20 @@ static int easu_dispatch_impl(const fsr1_image* in, const fsr1_image* out, const
   const bool s2 = con[0] == 0x3f000000u && con[1] == 0x3f000000u && con[2] == 0xbe800000u && con[3] == 0xbe800000u &&
                   !(flags & FSR1_FLAG_NO_FAST_PATHS) && !a.color.stages && kTileH % 16 == 0 && !((origin_x | origin_y) & 1);
   // (64 x 32 tiles for whole-image F launches that are large or overlapped: easu_s2_tall_tiles)
-  const bool tall = s2 && !(flags & (FSR1_FLAG_MATH_PACKED_FP16 | FSR1_FLAG_MATH_EXACT)) && !origin_x && !origin_y &&
-                    easu_s2_tall_tiles(out->width, out->height, out->frames, (flags & FSR1_FLAG_FRAMES_OVERLAP) != 0, device_cus());
+  bool tall = s2 && !(flags & (FSR1_FLAG_MATH_PACKED_FP16 | FSR1_FLAG_MATH_EXACT)) && !origin_x && !origin_y &&
+              easu_s2_tall_tiles(out->width, out->height, out->frames, (flags & FSR1_FLAG_FRAMES_OVERLAP) != 0, device_cus());
+  // Any other ratio, default arithmetic, plain pass, whole image: the generic kernel on 64 x 32 tiles with 512-thread workgroups when
+  // its pitched layout applies and the launch is large enough (easu_generic_tall_tiles) — the footprint is re-derived for the 32-row tile
+  if (!s2 && !(flags & (FSR1_FLAG_MATH_PACKED_FP16 | FSR1_FLAG_MATH_EXACT)) && !a.color.stages && !origin_x && !origin_y) {
+    const int fp_h32 = footprint_extent(out->height, 2 * kTileH, 0, sy, by);
+    const int pitch = easu_lds_pitch(a.fp_w, false, false);
+    if (fp_h32 > 0 && pitch && easu_generic_tall_tiles(out->width, out->height, out->frames, device_cus(), easu_lds_bytes(in->format, pitch, fp_h32)) &&
+        (long long)(fp_h32 + 1) * a.in.pitch < (1ll << 31)) {
+      tall = true;
+      a.fp_h = fp_h32;
+      a.tiles_y = (out->height + 2 * kTileH - 1) / (2 * kTileH);
+    }
+  }
   if (s2) {
     const int th = tall ? 2 * kTileH : kTileH;
     a.tiles_x = (out->width + 1 + kTileW - 1) / kTileW;

@@ -55,14 +55,25 @@ bool easu_s2_tall_tiles(int width, int height, int frames, bool overlapped, int 
   return overlapped || tiles16 >= 16ll * 8 * (cus > 0 ? cus : 256);  // sixteen residencies of 64 x 16 tiles (four 4K frames) and up
 }
 
+// The generic kernel (default arithmetic, pitched LDS layout) on 64 x 32 tiles with 512-thread workgroups (easu_kernel<..., WAVES = 8>):
+// whenever the taller footprint still lets a CU hold three workgroups (24 waves) and the launch has at least two workgroups per CU.
+// `lds_tall`: bytes of the 32-row tile's footprint in the pitched layout.
+bool easu_generic_tall_tiles(int width, int height, int frames, int cus, size_t lds_tall) {
+  if (const int forced = override_easu_s2_tall(); forced >= 0) return forced != 0 && lds_tall <= 160 * 1024;  // (test library only)
+  const long long tiles32 = (long long)((width + kTileW - 1) / kTileW) * ((height + 31) / 32) * frames;
+  return lds_tall * 3 <= 160 * 1024 && tiles32 >= 2ll * (cus > 0 ? cus : 256);
+}
+
 // s2: launch the exact-2x variant (the caller has checked con0 and laid the grid out for the shifted tiles); tall: on 64 x 32 tiles
 // (default arithmetic only: the EXACT variant's per-pixel form would spill at the seven-wave register budget with the longer loop).
 hipError_t easu_launch(const EasuArgs& a, int fmt, bool exact, bool s2, bool tall, hipStream_t stream) {
   const bool hdr = (a.flags & FSR1_FLAG_HDR_SQUARE) != 0;
   int pitch = s2 ? 0 : easu_lds_pitch(a.fp_w, exact, false);
-  if (pitch && easu_lds_bytes(fmt, pitch, a.fp_h) > 40 * 1024) pitch = 0;  // (tall footprints of anisotropic ratios: keep the dense layout's occupancy)
+  if (pitch && !tall && easu_lds_bytes(fmt, pitch, a.fp_h) > 40 * 1024) pitch = 0;  // (tall footprints of anisotropic ratios: keep the dense layout's occupancy)
+  if (!s2 && tall && !pitch) return hipErrorInvalidValue;  // (the host pairs the 512-thread tile with a pitched layout: easu_generic_tall_tiles)
 #define FSR1_LAUNCH_H(F, E, S, P) return hdr ? easu_launch_one<F, E, false, F, S, true, P>(a, stream) : easu_launch_one<F, E, false, F, S, false, P>(a, stream)
 #define FSR1_LAUNCH_T(F, E) return hdr ? easu_launch_one<F, E, false, F, true, true, 0, 32>(a, stream) : easu_launch_one<F, E, false, F, true, false, 0, 32>(a, stream)
+#define FSR1_LAUNCH_G8(F, P) return hdr ? easu_launch_one<F, false, false, F, false, true, P, 32, 8>(a, stream) : easu_launch_one<F, false, false, F, false, false, P, 32, 8>(a, stream)
 #define FSR1_LAUNCH_E(F)                              \
   do {                                                \
     if (s2 && tall && !exact) FSR1_LAUNCH_T(F, false); \
@@ -71,6 +82,9 @@ hipError_t easu_launch(const EasuArgs& a, int fmt, bool exact, bool s2, bool tal
       FSR1_LAUNCH_H(F, false, true, 0);               \
     }                                                 \
     if (exact) FSR1_LAUNCH_H(F, true, false, 0);      \
+    if (tall && pitch == 48) FSR1_LAUNCH_G8(F, 48);   \
+    if (tall && pitch == 56) FSR1_LAUNCH_G8(F, 56);   \
+    if (tall && pitch == 64) FSR1_LAUNCH_G8(F, 64);   \
     if (pitch == 48) FSR1_LAUNCH_H(F, false, false, 48); \
     if (pitch == 56) FSR1_LAUNCH_H(F, false, false, 56); \
     if (pitch == 64) FSR1_LAUNCH_H(F, false, false, 64); \
@@ -85,6 +99,7 @@ hipError_t easu_launch(const EasuArgs& a, int fmt, bool exact, bool s2, bool tal
   }
 #undef FSR1_LAUNCH_E
 #undef FSR1_LAUNCH_T
+#undef FSR1_LAUNCH_G8
 #undef FSR1_LAUNCH_H
 }
 

@@ -22,14 +22,22 @@ int easu_lds_pitch(int fp_w, bool exact, bool color);
 // pixel is the same function on the same values: bit-identical to S2 = false (tests/test_gpu_parity.py).
 // PITCH (generic variant only): 0 = dense LDS arrays of the tile's own footprint width; P = the row-interleaved layout with
 // the compile-time pitch P >= a.fp_w (easu_lds_carve_pitched): no LDS address arithmetic per tap row.
-// TH: rows of the output tile (16; 32 for exact-2x launches that are large or overlap other frames' launches, fsr1_easu.hip).
-template <int FMT, bool EXACT, bool COLOR = false, int FOUT = FMT, bool S2 = false, bool HDR = false, int PITCH = 0, int TH = kTileH>
+// TH: rows of the output tile (16; 32 for exact-2x launches that are large or overlap other frames' launches, and for the generic
+// kernel's 512-thread form, fsr1_easu.hip).
+// WAVES: waves of the workgroup (4; 8 = the generic kernel on 64 x 32 tiles, round 5): a wave always owns TH / WAVES = 4 rows of the
+// tile.  Why eight waves: the generic kernel is LDS-bound in workgroups per CU (a 1.5x tile's footprint is 23 KB for four waves: 7
+// workgroups; 1.3x: 30 KB, 5) and loses 2-2.5 % per workgroup it cannot hold (profiles/ab_r05/r5c6_ab_ldspad.log).  A 64 x 32 tile shares
+// its four apron rows between twice as many pixels — 40 KB for EIGHT waves at 1.5x, four workgroups = 8 waves per SIMD — and stages
+// a fifth less per pixel.  (The same tile with four waves, round 4, halved the waves per CU instead and lost.)
+template <int FMT, bool EXACT, bool COLOR = false, int FOUT = FMT, bool S2 = false, bool HDR = false, int PITCH = 0, int TH = kTileH, int WAVES = 4>
 // amdgpu_waves_per_eu(7, 8): at least seven waves per SIMD, i.e. at most 72 VGPRs.  Only the exact-2x default-arithmetic
 // variant is affected — its row-pair form would take 85 (five waves: 43.7 us) where 68 cost it nothing (41.6 us); every other
 // variant needs fewer than 64 anyway.
-__global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(7, 8))) easu_kernel(const EasuArgs a) {
+__global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(7, 8))) easu_kernel(const EasuArgs a) {
   typedef typename Pixel<FOUT>::T texel_t;
   static_assert(TH % 16 == 0, "a wave filters two quad rows per 16 tile rows");
+  static_assert(WAVES == 4 || (WAVES == 8 && TH == 32 && !S2), "eight waves: the generic kernel's 64 x 32 tile");
+  constexpr int kThreads = 64 * WAVES, kRowsPerWave = TH / WAVES;  // (shadows the default workgroup size)
   constexpr int kTileH = TH;  // (shadows the default tile height)
   constexpr bool kS2 = S2;
   constexpr int kS2W = kTileW / 2 + 3, kS2H = kTileH / 2 + 3;  // footprint of every exact-2x tile
@@ -124,7 +132,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(7
   const int row_stride = PITCH ? 2 * PITCH : fw;  // LDS records between footprint rows
   easu_stage_footprint<FMT, COLOR, EXACT, 0, 0, kThreads, PITCH>(l, a.in, in_frame, fx0, fy0, fw, fh, tid, &a.color);
 
-  // ---- phase 3: output pixels; a lane owns a column, a wave kTileH / 4 rows.  Which column: easu_lane_column — sixteen
+  // ---- phase 3: output pixels; a lane owns a column, a wave kRowsPerWave = 4 rows.  Which column: easu_lane_column — sixteen
   //      consecutive columns per LDS lane group, so that a group's texels stay within sixteen records (no bank conflicts) ----
   const int ox = ox0 + easu_lane_column(lane);
   if (ox >= a.out.width) return;
@@ -140,8 +148,8 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(7
   const bool stream = (a.flags & FSR1_FLAG_OUTPUT_STREAMING) != 0;
 
 #pragma unroll 1
-  for (int r = 0; r < kTileH / 4; ++r) {
-    const int oy = oy0 + wave * (kTileH / 4) + r;
+  for (int r = 0; r < kRowsPerWave; ++r) {
+    const int oy = oy0 + wave * kRowsPerWave + r;
     if (oy >= a.out.height) break;
     float ppy = (float)(oy + a.origin_y) * c0y + c0w;  // :324-326
     const float fpy = floorf(ppy);
@@ -161,12 +169,12 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(7
   }
 }
 
-template <int FMT, bool EXACT, bool COLOR, int FOUT, bool S2 = false, bool HDR = false, int PITCH = 0, int TH = kTileH>
+template <int FMT, bool EXACT, bool COLOR, int FOUT, bool S2 = false, bool HDR = false, int PITCH = 0, int TH = kTileH, int WAVES = 4>
 hipError_t easu_launch_one(const EasuArgs& a, hipStream_t stream) {
-  const dim3 grid((unsigned)(a.tiles_x * a.tiles_y * a.frames)), block(kThreads);
+  const dim3 grid((unsigned)(a.tiles_x * a.tiles_y * a.frames)), block(64 * WAVES);
   const size_t lds = easu_lds_bytes(FMT, PITCH ? PITCH : a.fp_w, a.fp_h);
-  if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&easu_kernel<FMT, EXACT, COLOR, FOUT, S2, HDR, PITCH, TH>), lds); e != hipSuccess) return e;
-  hipLaunchKernelGGL((easu_kernel<FMT, EXACT, COLOR, FOUT, S2, HDR, PITCH, TH>), grid, block, lds, stream, a);
+  if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&easu_kernel<FMT, EXACT, COLOR, FOUT, S2, HDR, PITCH, TH, WAVES>), lds); e != hipSuccess) return e;
+  hipLaunchKernelGGL((easu_kernel<FMT, EXACT, COLOR, FOUT, S2, HDR, PITCH, TH, WAVES>), grid, block, lds, stream, a);
   return hipGetLastError();
 }
 

@@ -256,7 +256,9 @@ typedef struct fsr1_params {
                                           otherwise the two dispatches whenever the launch has more than 3 Mpixel of output
                                           (4K at 1.5x: 80.7 vs 88.8 us) and the fused launch below that, where a frame is
                                           launch-bound, for every arithmetic (FSR1_FLAG_MATH_PACKED_FP16 has a fused launch
-                                          too) — and only where the fused tile fits a CU's LDS (up to about 1.9x
+                                          too; at exactly 2x its quad form is taken up to 4 Mpixel and from 60 Mpixel of output
+                                          up — round 5: 720p -> 1440p 50.9 vs 47.0 us, sixteen 8K frames 5.45 vs 5.24 ms, one 4K
+                                          frame the other way, 93.7 vs 95.6) — and only where the fused tile fits a CU's LDS (up to about 1.9x
                                           minification; beyond that auto keeps the two dispatches); with intermediary == NULL
                                           it is the fused launch */
   uint32_t flags;                      /* FSR1_FLAG_MATH_*, FSR1_FLAG_RCAS_DENOISE / _PASSTHROUGH_ALPHA, FSR1_FLAG_OUTPUT_* (of the pass that writes `out`) */

@@ -177,7 +177,11 @@ def test_upscale_plan_auto_rule(fsr):
 
     assert plan(1920, 1080, 3840, 2160) == 1                      # exactly 2x: the quad-form single launch
     assert plan(1920, 1080, 3840, 2160, flags=1 << 8) == 0        # NO_FAST_PATHS: generic kernels, 8.3 Mpixel -> two dispatches
-    assert plan(1920, 1080, 3840, 2160, flags=1 << 5) == 0        # packed fp16 has no quad-form fused kernel
+    assert plan(1920, 1080, 3840, 2160, flags=1 << 5) == 0        # packed fp16, one 4K frame: the two H dispatches (93.7 vs 95.6 us)
+    assert plan(1280, 720, 2560, 1440, flags=1 << 5) == 1         # ... up to 4 Mpixel its exact-2x fused launch (50.9 vs 47.0 us)
+    assert plan(1920, 1080, 3840, 2160, flags=1 << 5, frames=4) == 0 and plan(1920, 1080, 3840, 2160, flags=1 << 5, frames=8) == 1  # and from 60 Mpixel up
+    assert plan(3840, 2160, 7680, 4320, flags=1 << 5, frames=16) == 1 and plan(3840, 2160, 7680, 4320, flags=1 << 5) == 0
+    assert plan(1280, 720, 2560, 1440, flags=(1 << 5) | (1 << 8)) == 0  # (NO_FAST_PATHS: the generic H kernels, 3.7 Mpixel -> two dispatches)
     assert plan(1920, 1080, 3840, 2160, stages=1) == 0            # colour stages neither
     assert plan(2560, 1440, 3840, 2160) == 0                      # 1.5x at 4K: two dispatches
     assert plan(1280, 720, 1920, 1080) == 1                       # 1.5x at 1080p: launch-bound, fused

@@ -703,3 +703,47 @@ def test_easu_exact_2x_tall_tiles(fsr, shape):
             hint = torch.zeros_like(want)
             fsr.easu(src, hint, flags=flags | fsr.FLAG_FRAMES_OVERLAP)  # the rule's own choice under the overlap hint: tall
             assert torch.equal(hint, want), (str(src.dtype), flags, "overlap hint")
+
+
+@pytest.mark.parametrize("shape", [(97, 160, 146, 240), (120, 68, 204, 116), (200, 120, 260, 156), (64, 40, 69, 43), (33, 17, 57, 29), (300, 170, 450, 255)],
+                         ids=lambda s: "%dx%d_to_%dx%d" % s)
+def test_easu_generic_tall_tiles(fsr, shape):
+    """Ratios without an exact-2x form run the generic kernel; large launches take its 512-thread workgroups on 64 x 32 tiles
+    (easu_kernel<..., TH = 32, WAVES = 8>, round 5).  Forced here on small ragged images and batches at 1.5x / 1.7x / 1.3x / 1.08x — bit-
+    identical to the 64 x 16 tiles of 256 threads, in RGBA16F / RGBA32F / RGBA8 storage and with the HDR square; and the rule's own choice
+    on a frame large enough to take the tall tiles equals the short tiles as well."""
+    iw, ih, ow, oh = shape
+    n = 2
+    src16 = dev(np.stack([frames.synthetic_frame(iw, ih, k=90 + f, dtype=np.float16) for f in range(n)]))
+    for src in (src16, src16.float(), (src16.float().clamp(0, 1) * 255 + 0.5).to(torch.uint8)):
+        for flags in (0, fsr.FLAG_HDR_SQUARE | fsr.FLAG_OUTPUT_STREAMING):
+            with fsr._lib.test_hooks() as lib:  # libfsr1_hip_test.so (include/fsr1_hip_test.h)
+                lib.fsr1_debug_easu_tall_tiles(0)
+                want = torch.zeros(n, oh, ow, 4, dtype=src.dtype, device="cuda")
+                fsr.easu(src, want, con=fsr.FsrEasuCon(iw, ih, iw, ih, ow, oh), flags=flags)
+                lib.fsr1_debug_easu_tall_tiles(1)
+                big = torch.full((n, oh + 1, ow + 5, 4), 7, dtype=src.dtype, device="cuda")
+                got = big[:, :oh, :ow]
+                fsr.easu(src, got, con=fsr.FsrEasuCon(iw, ih, iw, ih, ow, oh), flags=flags)
+                torch.cuda.synchronize()
+            assert bool((big[:, oh:] == 7).all()) and bool((big[:, :, ow:] == 7).all()), "wrote outside the output view"
+            assert torch.equal(got, want), (str(src.dtype), flags)
+
+
+def test_easu_generic_tall_tiles_rule_on_a_large_frame(fsr):
+    """2560x1440 -> 3840x2160: the host's rule takes the 512-thread tiles (2040 workgroups); the same frame with the rule overridden to
+    the 256-thread tiles is the same image, and so is the EXACT-free generic path of the two-dispatch pipeline (RCAS on top)."""
+    iw, ih, ow, oh = 2560, 1440, 3840, 2160
+    src = dev(frames.synthetic_frame(iw, ih, k=5, dtype=np.float16))
+    con = fsr.FsrEasuCon(iw, ih, iw, ih, ow, oh)
+    rule = torch.zeros(oh, ow, 4, dtype=torch.float16, device="cuda")
+    fsr.easu(src, rule, con=con)
+    with fsr._lib.test_hooks() as lib:
+        lib.fsr1_debug_easu_tall_tiles(0)
+        short = torch.zeros_like(rule)
+        fsr.easu(src, short, con=con)
+        lib.fsr1_debug_easu_tall_tiles(1)
+        tall = torch.zeros_like(rule)
+        fsr.easu(src, tall, con=con)
+        torch.cuda.synchronize()
+    assert torch.equal(rule.view(torch.int16), short.view(torch.int16)) and torch.equal(tall.view(torch.int16), short.view(torch.int16))

@@ -110,6 +110,10 @@ def test_bench_self_launch_two_ranks_on_the_visible_gpus():
     line = _bench_line(cmd, env, timeout=900)
     assert line["n_gpus"] == 2 and line["config"]["world_size_seen"] == 2 and len(line["per_rank_seconds"]) == 2
     assert line["config"]["oversubscribed"] == (not two) and line["value"] > 0 and "roofline" in line
+    # round 5: per-rank clock / power travel in one more counters-only collective; at N > 1 only the headline regions run
+    assert len(line["per_rank_mhz"]) == 2 and len(line["per_rank_watts"]) == 2
+    assert line.get("also_measured") is None and "skipped at n_gpus > 1" in line["also_measured_note"]
+    assert "latency_us" not in line and "cpu_baseline" not in line and line["parity_class"] == "F-default"
 
 
 @pytest.mark.gpu
