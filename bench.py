@@ -121,9 +121,12 @@ class Telemetry:
             except Exception:
                 pass
             if node is None:  # no PCI ids from the runtime: the dev_index-th AMD GPU with a hwmon node, in PCI order
-                cands = sorted(os.path.realpath(c) for c in glob.glob("/sys/class/drm/card*/device")
-                               if open(os.path.join(c, "vendor")).read().strip() == "0x1002" and glob.glob(os.path.join(c, "hwmon", "hwmon*")))
-                cands = sorted(set(cands))
+                def amd_gpu(c):  # (partition nodes — /sys/devices/platform/amdgpu_xcp_* — have no vendor file: skipped)
+                    try:
+                        return open(os.path.join(c, "vendor")).read().strip() == "0x1002" and bool(glob.glob(os.path.join(c, "hwmon", "hwmon*")))
+                    except OSError:
+                        return False
+                cands = sorted(set(os.path.realpath(c) for c in glob.glob("/sys/class/drm/card*/device") if amd_gpu(c)))
                 if dev_index < len(cands):
                     node, self.source = cands[dev_index], "sysfs hwmon of %s (device %d in PCI order)" % (os.path.basename(cands[dev_index]), dev_index)
             if node:
@@ -809,6 +812,20 @@ def main():
             also["quality_1440p_to_4k_two_pass"] = also_entry(q_step, "2560x1440 -> 3840x2160 (1.5x, BASELINE configs[2]'s shape), EASU + RCAS as two dispatches, generic kernels",
                                                               px_per_step=out_w * out_h, fn=pipe and piped(math_flags, 0, inputs=q_in))
             del q_in
+            # ... and the reference sample's true-ratio presets at a 4K target (sample/src/DX12/FSRSample.h:79-95, PDF p.10): "Ultra Quality"
+            # 1.3x and "Balanced" 1.7x — with 1.5x above, three of its four quality modes run the generic kernel
+            for key, (p_w, p_h, label) in {"ultra_quality_1662p_to_4k_two_pass": (2954, 1662, "1.3x 'Ultra Quality'"),
+                                           "balanced_1270p_to_4k_two_pass": (2259, 1270, "1.7x 'Balanced'")}.items():
+                p_in = [torch.roll(torch.from_numpy(fsr.frames.synthetic_frame(p_w, p_h, k=4 + 16 * rank)).to(device), shifts=(3 * s, 5 * s), dims=(0, 1)).contiguous().unsqueeze(0)
+                        for s in range(ring)]
+                p_con = fsr.FsrEasuCon(p_w, p_h, p_w, p_h, out_w, out_h)
+
+                def p_step(i, p_in=p_in, p_con=p_con):
+                    fsr.easu(p_in[i % ring], mid, con=p_con, flags=math_flags)
+                    fsr.rcas(mid, dsts[i % ring], con=rcas_con, flags=math_flags)
+                also[key] = also_entry(p_step, "%dx%d -> 3840x2160 (%s, the sample's true-ratio preset), EASU + RCAS as two dispatches, generic kernels" % (p_w, p_h, label),
+                                       px_per_step=out_w * out_h, fn=pipe and piped(math_flags, 0, inputs=p_in))
+                del p_in
 
     # ---- single-frame latency (N = 1): submit -> completion of ONE frame on a warm, otherwise idle GPU — the reference's actual
     #      usage, one Upscale per display refresh (SampleRenderer.cpp:705-709), which the pipelined headline does not represent ----

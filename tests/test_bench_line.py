@@ -66,3 +66,26 @@ def test_pipelined_line_is_judged_against_the_one_stream_step():
     bad["config"] = {"streams": 2, "one_stream": {"ms_per_step": 0.0656}}
     bad["also_measured"]["fused"]["one_stream"] = {"ms_per_step": 0.0605}
     assert len(bench.check_stopwatch(bad)) == 2 and bad["stopwatch_suspect"] is True
+
+
+def test_telemetry_summary_and_gather_without_a_process_group():
+    """bench.Telemetry reduces its samples over labelled spans (median MHz, mean W) and never fails a run when a box exposes no
+    sysfs files; bench.gather_pairs is the identity at world size 1 and maps "not read" to null (round 5: per-rank clock / power)."""
+    import bench
+
+    class _NoGpuTorch:
+        class cuda:
+            @staticmethod
+            def get_device_properties(i):
+                raise RuntimeError("no GPU here")
+    t = bench.Telemetry(_NoGpuTorch, 0)
+    t.close()
+    assert t.summary("headline") == (None, None, 0)
+    t.samples = [(0.5, 100.0, 200.0), (1.5, 2100.0, 1300.0), (1.6, 2200.0, 1400.0), (1.7, 2000.0, None), (3.0, 90.0, 150.0)]
+    t.spans = {"headline": [(1.0, 2.0)], "idle": [(2.5, 3.5)]}
+    assert t.summary("headline") == (2100.0, 1350.0, 3)
+    assert t.summary("idle") == (90.0, 150.0, 1)
+    assert t.summary("nothing") == (None, None, 0)
+    import torch
+    mhz, watts = bench.gather_pairs(2100.0, None, torch.device("cpu"))
+    assert mhz == [2100.0] and watts == [None]

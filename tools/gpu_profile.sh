@@ -12,7 +12,7 @@ RAW=/tmp/prof_$TAG
 rm -rf "$RAW"; mkdir -p "$OUT" "$RAW"
 export TMPDIR=/tmp
 STEPS=${STEPS:-300}; PMC_STEPS=${PMC_STEPS:-16}
-BENCH="python $ROOT/bench.py --no-cpu-baseline --no-cold-rcas --no-also $*"
+BENCH="python $ROOT/bench.py --no-cpu-baseline --no-cold-rcas --no-also --no-latency --no-steady --no-parity $*"
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$RAW/stats" -o r -- $BENCH --steps $STEPS --warmup 30 > "$RAW/stats.log" 2>&1
 grep -h '^{' "$RAW/stats.log" | tail -1 > "$OUT/$TAG.line"
@@ -30,7 +30,7 @@ for ((i=0;i<${#args[@]};i++)); do
 done
 python tools/prof_summary.py --out "$OUT/$TAG" --stats "$RAW/stats" --pmc "$RAW/fetch" --pmc "$RAW/write" --pmc "$RAW/tcc" --pmc "$RAW/sq1" --pmc "$RAW/sq2" \
   --workload "$WL" --pipeline "$PL" --math "$MATH" --storage "$ST" --lib "$ROOT/fidelityfx-fsr_amd/libfsr1_hip.so" --bench-line "$OUT/$TAG.line" \
-  --command "tools/gpu_profile.sh $TAG $*  (rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline --no-cold-rcas --no-also $* --steps $STEPS --warmup 30; PMC in separate --pmc passes of $((PMC_STEPS+4)) steps)" \
+  --command "tools/gpu_profile.sh $TAG $*  (rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline --no-cold-rcas --no-also --no-latency --no-steady --no-parity $* --steps $STEPS --warmup 30; PMC in separate --pmc passes of $((PMC_STEPS+4)) steps)" \
   --note "${NOTE:-}" > "$RAW/summary.log" 2>&1 || cat "$RAW/summary.log"
 find "$RAW/stats" -name '*kernel_stats.csv' | head -1 | xargs -I{} cp {} "$OUT/${TAG}_kernel_stats.csv"
 tail -2 "$RAW/summary.log"; cat "$OUT/$TAG.line" | cut -c1-300
