@@ -194,9 +194,11 @@ def test_easu_h_exact_2x_variant_is_bit_identical(fsr, port, shape):
 
 def test_upscale_auto_with_packed_fp16(fsr, port):
     """FSR_Filter.OnCreate(slowFallback=False, fused="auto") — the reference's default permutation with the pipeline left
-    to the library (round 1 failed here: auto picked a fused launch that did not exist for packed-fp16).  A small frame takes
-    the fused H launch, a frame above 3 Mpixel the two H dispatches; either way the image is FsrRcasH(FsrEasuH(input))."""
-    for (iw, ih, ow, oh), expect_two_pass in (((160, 90, 320, 180), False), ((1280, 720, 2560, 1440), True)):
+    to the library (round 1 failed here: auto picked a fused launch that did not exist for packed-fp16).  At exactly 2x a frame of
+    up to 4 Mpixel takes the fused H launch (round 5: 720p -> 1440p 50.9 vs 47.0 us), a 4K frame the two H dispatches (93.7 vs 95.6),
+    a 1.5x frame above 3 Mpixel the two dispatches as well; either way the image is FsrRcasH(FsrEasuH(input))."""
+    for (iw, ih, ow, oh), expect_two_pass in (((160, 90, 320, 180), False), ((1280, 720, 2560, 1440), False), ((1920, 1080, 3840, 2160), True),
+                                              ((1600, 900, 2400, 1350), True)):
         img = frames.synthetic_frame(iw, ih, k=6, dtype=np.float16)
         src = dev(img)
         dst = torch.zeros(oh, ow, 4, dtype=torch.float16, device="cuda")
