@@ -949,6 +949,10 @@ def main():
                                  "launch's latency and the closing synchronize are 1-6 % of it, so single regions scatter by that much)",
                        "pipeline": args.pipeline, "storage": args.storage, "color_stages": args.stages, "hip_graph_steps": args.graph, "rcas_sharpness_stops": 0.25,
                        "parallelism": "independent frames per GPU, counters-only collective"},
+            # the headline `value` is the pipelined figure (`streams` HIP streams per GPU, the product's way to run a frame stream); the same K
+            # steps on ONE in-order stream — the method of rounds 1-3, and what the kernels' durations add up to — at the top level beside it
+            "streams": args.streams,
+            "one_stream": {"value": round(total["pixels"] / median(one_regions) / 1e6, 1), "ms_per_step": round(median(one_regions) * 1e3 / args.steps, 5)},
             "per_rank_seconds": [round(t, 6) for t in per_rank_seconds],
             # shader clock (median MHz) and package power (mean W) every rank's GPU showed under the headline's load (second half of the
             # ramp, warm-up, timed regions, steady-state run), read from the amdgpu driver's sysfs files by a host thread; null where a
