@@ -560,7 +560,10 @@ def main():
     # (managed=False: the bare C ABI — the buffers live for the whole run and every timed region is bracketed by synchronizes)
     pipe = fsr.Pipeline(args.streams, managed=False) if args.streams > 1 else None
     if pipe is not None and args.pipeline == "two-pass":
-        pipe.reserve(out_bytes)  # no allocation inside a timed region or a graph capture
+        # no allocation inside a timed region or a graph capture (a batch whose per-frame intermediaries fit the Infinity Cache together is
+        # submitted frame by frame, fsr1_pipeline_upscale: one frame's worth per slot is then enough)
+        split = frames > 1 and (out_bytes // frames) * args.streams <= (256 << 20)
+        pipe.reserve(out_bytes // frames if split else out_bytes)
 
     def piped(flags, fused, use_rcas=True, inputs=None, con_stages=None):
         def fn(i):

@@ -409,15 +409,18 @@ class Pipeline:
         rw, rh = render_size if render_size is not None else (i.width, i.height)
         p = fsr1_params(float(rw), float(rh), int(bool(use_rcas)), float(sharpness), int(bool(hdr)), int(fused) if use_rcas else 0, int(flags))
         sp, _keep = _stages(stages)
-        slot_stream = None
+        used = ()
         if self.managed:
-            slot_stream = self._slot_stream(self.next_slot())
-            slot_stream.wait_stream(torch.cuda.current_stream())  # after the producer of src / the last user of dst on the caller's stream
+            # after the producer of src / the last user of dst on the caller's stream: the slot this submission takes — every slot for a
+            # batch, which the library may submit frame by frame over all of them (fsr1_pipeline_upscale)
+            used = [self._slot_stream(self.next_slot())] if o.frames == 1 or self.streams == 1 else [self._slot_stream(k) for k in range(self.streams)]
+            for st in used:
+                st.wait_stream(torch.cuda.current_stream())
         _lib.check(_lib.load().fsr1_pipeline_upscale(self._h, ctypes.byref(i), ctypes.byref(o), ctypes.byref(p), sp))
         if self.managed and not torch.cuda.is_current_stream_capturing():  # (a captured submission runs at replay time: the graph's owner keeps its tensors)
-            while self._live and self._live[0][0].query():  # submissions that have left the device no longer need their tensors held
+            while self._live and all(e.query() for e in self._live[0][0]):  # submissions that have left the device no longer need their tensors held
                 self._live.pop(0)
-            self._live.append((slot_stream.record_event(), (src, dst, stages)))
+            self._live.append(([st.record_event() for st in used], (src, dst, stages)))
         return dst
 
     def fork(self, stream=None):

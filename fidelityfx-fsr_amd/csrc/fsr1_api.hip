@@ -783,6 +783,28 @@ int fsr1_pipeline_upscale(fsr1_pipeline* p, const fsr1_image* in, const fsr1_ima
   if (stages && !stages->stages) stages = nullptr;
   UpscalePlan plan;
   if (int rc = upscale_decide("pipeline_upscale", in, true, out, params, stages != nullptr, &plan)) return rc;
+  // A batch whose frames go through two dispatches is submitted FRAME BY FRAME over the pipeline's slots when the per-frame
+  // intermediaries of all slots fit the 256 MB Infinity Cache together (three 4K RGBA16F frames: 199 MB): every frame's RCAS then
+  // reads its intermediary from the cache, and frame f's RCAS runs beside frame f + 1's EASU, where one launch pair for the whole
+  // batch sends a 531 MB intermediary through HBM and serialises the two passes (round 5, 8-frame 2560x1440 -> 3840x2160 batch,
+  // profiles/ab_r05/r5c8_batch_vs_frames.log: 111.6 Gpix/s as launch pairs over three streams, 118.5 frame by frame).  Frame f of the batch
+  // runs on slot (next_slot + f) mod N; the frames are the same kernels on the same values as in one launch: bit-identical
+  // (tests/test_gpu_pipeline.py).  8K frames (265 MB each) and fused launches keep the single launch.
+  if (plan.pipeline == 0 && out->frames > 1 && p->n > 1 &&
+      (size_t)out->width * pixel_bytes(out->format) * (size_t)out->height * (size_t)p->n <= ((size_t)256 << 20)) {
+    ImageView vi, vo;
+    if (int rc = check_image(in, "pipeline_upscale input", &vi)) return rc;
+    if (int rc = check_image(out, "pipeline_upscale output", &vo)) return rc;
+    for (int f = 0; f < out->frames; ++f) {
+      fsr1_image fi = *in, fo = *out;
+      fi.data = vi.base + (long long)f * vi.frame_stride;
+      fo.data = vo.base + (long long)f * vo.frame_stride;
+      fi.frames = fo.frames = 1;
+      fi.frame_stride_bytes = fo.frame_stride_bytes = 0;
+      if (int rc = fsr1_pipeline_upscale(p, &fi, &fo, params, stages)) return rc;
+    }
+    return FSR1_OK;
+  }
   const int slot = p->next;
   fsr1_image mid_img;
   const fsr1_image* mid_p = nullptr;

@@ -307,14 +307,17 @@ int fsr1_upscale_plan(const fsr1_image* in, int32_t have_intermediary, const fsr
 typedef struct fsr1_pipeline fsr1_pipeline; /* opaque */
 int fsr1_pipeline_create(fsr1_pipeline** pipeline, int32_t streams /* 1 .. 8 */);
 /* fsr1_upscale_ex for one frame (or batch) on the pipeline's next stream, with that stream's own intermediary
- * (params->fused = 2 decides as if an intermediary was supplied).  Asynchronous: when the slot's intermediary is too small it is
+ * (params->fused = 2 decides as if an intermediary was supplied).  A BATCH that takes the two dispatches is submitted frame by frame —
+ * frame f on slot (next_slot + f) mod N, the slot counter advancing by the frame count — whenever the per-frame intermediaries of all
+ * N slots fit the 256 MB Infinity Cache together (e.g. 4K RGBA16F frames on three streams): +6 % on an 8-frame 1440p -> 4K batch,
+ * the same pixels (round 5); larger frames and fused launches stay one launch on one slot.  Asynchronous: when the slot's intermediary is too small it is
  * re-allocated in stream order on the slot's own stream (hipFreeAsync / hipMallocAsync — no host block, no device-wide
  * synchronisation).  While the stream is being captured into a hipGraph a growth is refused with FSR1_ERR_INVALID_ARGUMENT and a
  * message naming the size to reserve: call fsr1_pipeline_reserve before the capture. */
 int fsr1_pipeline_upscale(fsr1_pipeline* pipeline, const fsr1_image* in, const fsr1_image* out, const fsr1_params* params,
                           const fsr1_color_stages* stages);
-/* Pre-sizes every slot's intermediary to at least bytes_per_stream (= out width x height x bytes per pixel x frames of the largest
- * frame the two-dispatch pipeline will see), so that no later submission allocates: what a host does once before capturing frames
+/* Pre-sizes every slot's intermediary to at least bytes_per_stream (= out width x height x bytes per pixel of the largest frame the
+ * two-dispatch pipeline will see; x frames for batches that are not split, see fsr1_pipeline_upscale), so that no later submission allocates: what a host does once before capturing frames
  * into a hipGraph, or to keep allocation out of its frame loop.  Intermediaries never shrink. */
 int fsr1_pipeline_reserve(fsr1_pipeline* pipeline, size_t bytes_per_stream);
 /* The slot (0 .. streams - 1) the next fsr1_pipeline_upscale will run on; -1 for a null pipeline.  See the aliasing rule above. */

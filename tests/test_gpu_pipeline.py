@@ -205,6 +205,38 @@ def test_intermediary_grows_in_stream_order_without_blocking(fsr):
     pipe.close()
 
 
+def test_batches_are_submitted_frame_by_frame_when_their_intermediaries_fit_the_cache(fsr):
+    """A batch that takes the two dispatches goes through the pipeline frame by frame (frame f on slot (next_slot + f) mod N): same
+    pixels as the batch in one launch pair on one stream, the slot counter advances by the frame count, strided batches (pitch and
+    frame stride) included; a fused batch and a one-stream pipeline keep the single launch (the counter advances by one)."""
+    iw, ih, ow, oh, n = 240, 135, 360, 203, 5
+    src = dev(np.stack([frames.synthetic_frame(iw, ih, k=60 + f, dtype=np.float16) for f in range(n)]))
+    want = torch.zeros(n, oh, ow, 4, dtype=torch.float16, device="cuda")
+    mid = torch.zeros_like(want)
+    fsr.easu(src, mid, con=fsr.FsrEasuCon(iw, ih, iw, ih, ow, oh))
+    fsr.rcas(mid, want, sharpness=0.25)
+    torch.cuda.synchronize()
+    pipe = fsr.Pipeline(3)
+    big = torch.full((n, oh + 3, ow + 7, 4), 5.0, dtype=torch.float16, device="cuda")
+    got = big[:, :oh, :ow]  # row pitch and frame stride larger than the image
+    assert pipe.next_slot() == 0
+    pipe.upscale(src, got, fused=0)
+    assert pipe.next_slot() == n % 3
+    pipe.upscale(src, got, fused=1)  # a fused batch: one launch, one slot
+    assert pipe.next_slot() == (n + 1) % 3
+    pipe.synchronize()
+    assert torch.equal(got.view(torch.int16), want.view(torch.int16))
+    assert bool((big[:, oh:] == 5.0).all()) and bool((big[:, :, ow:] == 5.0).all())
+    pipe.close()
+    one = fsr.Pipeline(1)
+    got.fill_(0)
+    one.upscale(src, got, fused=0)
+    assert one.next_slot() == 0
+    one.synchronize()
+    assert torch.equal(got.view(torch.int16), want.view(torch.int16))
+    one.close()
+
+
 def test_managed_pipeline_orders_itself_after_the_current_torch_stream(fsr):
     """Pipeline(managed=True), the default: no fork() — each submission's stream waits for what the current torch stream holds (the
     producer of the input), and the tensors stay referenced while in flight even if the caller drops them."""
