@@ -24,6 +24,7 @@ FLAG_RCAS_DENOISE = 1 << 1
 FLAG_RCAS_PASSTHROUGH_ALPHA = 1 << 2
 FLAG_MATH_EXACT = 1 << 4
 FLAG_MATH_PACKED_FP16 = 1 << 5
+FLAG_MATH_STRICT = 1 << 6
 FLAG_NO_FAST_PATHS = 1 << 8
 FLAG_OUTPUT_STREAMING = 1 << 9
 FLAG_OUTPUT_CACHED = 1 << 10
@@ -251,7 +252,7 @@ def upscale_band(src, dst_band, out_size, band, mid=None, sharpness=0.25, flags=
     mid = mid[:m1 - m0]
     # FSR_Filter.cpp:107: EASU's Sample.x is 0 when RCAS follows — the HDR square, RCAS options and the store policy of the
     # final image belong to the RCAS dispatch only (the fused launch squares once, and so must the two dispatches)
-    easu_flags = flags & (FLAG_MATH_EXACT | FLAG_MATH_PACKED_FP16 | FLAG_NO_FAST_PATHS)
+    easu_flags = flags & (FLAG_MATH_EXACT | FLAG_MATH_PACKED_FP16 | FLAG_MATH_STRICT | FLAG_NO_FAST_PATHS)
     easu_band(src, mid, con, origin=(0, m0), flags=easu_flags, stream=stream)
     rcas_band(mid[y0 - m0:y0 - m0 + (y1 - y0)], dst_band, sharpness=sharpness, rows_above=int(m0 < y0), rows_below=int(m1 > y1), flags=flags, stream=stream)
     return dst_band

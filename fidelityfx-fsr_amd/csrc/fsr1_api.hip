@@ -12,7 +12,8 @@
 #include "fsr1_device.h"
 
 namespace fsr1 {
-hipError_t easu_launch(const EasuArgs& a, int fmt, bool exact, bool s2, bool tall, hipStream_t stream);
+hipError_t easu_launch(const EasuArgs& a, int fmt, bool exact, bool s2, bool tall, hipStream_t stream, bool strict);
+size_t easu_strict_lds_bytes(int fmt, int fp_w, int fp_h, int tile_h);
 bool easu_s2_tall_tiles(int width, int height, int frames, bool overlapped, int cus);
 bool easu_generic_tall_tiles(int width, int height, int frames, int cus, size_t lds_tall);
 int easu_lds_pitch(int fp_w, bool exact, bool color);
@@ -181,13 +182,15 @@ static int check_grid(const char* who, int tiles_x, int tiles_y, int frames) {
 }
 
 static const uint32_t kKnownFlags = FSR1_FLAG_HDR_SQUARE | FSR1_FLAG_RCAS_DENOISE | FSR1_FLAG_RCAS_PASSTHROUGH_ALPHA |
-                                    FSR1_FLAG_MATH_EXACT | FSR1_FLAG_MATH_PACKED_FP16 | FSR1_FLAG_NO_FAST_PATHS |
+                                    FSR1_FLAG_MATH_EXACT | FSR1_FLAG_MATH_PACKED_FP16 | FSR1_FLAG_MATH_STRICT | FSR1_FLAG_NO_FAST_PATHS |
                                     FSR1_FLAG_OUTPUT_STREAMING | FSR1_FLAG_OUTPUT_CACHED | FSR1_FLAG_FRAMES_OVERLAP;
 
 static int check_flags(uint32_t flags) {
   if (flags & ~kKnownFlags) return fail(FSR1_ERR_INVALID_ARGUMENT, "unknown flag bits 0x%x", flags & ~kKnownFlags);
   if ((flags & FSR1_FLAG_MATH_EXACT) && (flags & FSR1_FLAG_MATH_PACKED_FP16))
     return fail(FSR1_ERR_INVALID_ARGUMENT, "FSR1_FLAG_MATH_EXACT and FSR1_FLAG_MATH_PACKED_FP16 are exclusive");
+  if ((flags & FSR1_FLAG_MATH_STRICT) && (flags & (FSR1_FLAG_MATH_EXACT | FSR1_FLAG_MATH_PACKED_FP16)))
+    return fail(FSR1_ERR_INVALID_ARGUMENT, "FSR1_FLAG_MATH_STRICT is exclusive with FSR1_FLAG_MATH_EXACT and FSR1_FLAG_MATH_PACKED_FP16");
   if ((flags & FSR1_FLAG_OUTPUT_STREAMING) && (flags & FSR1_FLAG_OUTPUT_CACHED))
     return fail(FSR1_ERR_INVALID_ARGUMENT, "FSR1_FLAG_OUTPUT_STREAMING and FSR1_FLAG_OUTPUT_CACHED are exclusive");
   return FSR1_OK;
@@ -337,6 +340,10 @@ static int easu_dispatch_impl(const fsr1_image* in, const fsr1_image* out, const
   if (a.color.stages && (flags & FSR1_FLAG_MATH_PACKED_FP16)) return fail(FSR1_ERR_UNSUPPORTED, "easu: colour stages run with the F (binary32) arithmetic");
   if (in->frames != out->frames) return fail(FSR1_ERR_INVALID_ARGUMENT, "easu: frame counts differ (%d vs %d)", in->frames, out->frames);
   if (overlaps(in, a.in, out, a.out)) return fail(FSR1_ERR_INVALID_ARGUMENT, "easu: input and output overlap");
+  // F-strict promises EXACT's stored image: where there is no conversion to test against (RGBA32F stores the binary32 result itself)
+  // or no strict variant is built (`c *= c`, colour stages), the EXACT kernels deliver it directly
+  if ((flags & FSR1_FLAG_MATH_STRICT) && (in->format == FSR1_FORMAT_RGBA32F || (flags & FSR1_FLAG_HDR_SQUARE) || a.color.stages))
+    flags = (flags & ~(uint32_t)FSR1_FLAG_MATH_STRICT) | FSR1_FLAG_MATH_EXACT;
   memcpy(a.con, con, sizeof a.con);
   float sx, sy, bx, by;
   memcpy(&sx, &con[0], 4);
@@ -351,6 +358,9 @@ static int easu_dispatch_impl(const fsr1_image* in, const fsr1_image* out, const
   if (easu_lds_bytes(in->format, a.fp_w, a.fp_h) > 160 * 1024)
     return fail(FSR1_ERR_UNSUPPORTED, "easu: input/output ratio (%g, %g) needs a %dx%d texel footprint per tile, beyond the LDS budget "
                                       "(EASU is an upscaler; ratios up to ~3x minification are supported)", sx, sy, a.fp_w, a.fp_h);
+  if ((flags & FSR1_FLAG_MATH_STRICT) && easu_strict_lds_bytes(in->format, a.fp_w, a.fp_h, kTileH) > 160 * 1024)  // (no room for the queue: EXACT)
+    flags = (flags & ~(uint32_t)FSR1_FLAG_MATH_STRICT) | FSR1_FLAG_MATH_EXACT;
+  const bool strict = (flags & FSR1_FLAG_MATH_STRICT) != 0;
   if ((long long)(a.fp_h + 1) * a.in.pitch >= (1ll << 31))  // staging addresses texels as row base + 32-bit offset
     return fail(FSR1_ERR_UNSUPPORTED, "easu: input row pitch %lld too large for a %d-row footprint", a.in.pitch, a.fp_h);
   a.tiles_x = (out->width + kTileW - 1) / kTileW;
@@ -374,7 +384,9 @@ static int easu_dispatch_impl(const fsr1_image* in, const fsr1_image* out, const
   if (!s2 && !(flags & (FSR1_FLAG_MATH_PACKED_FP16 | FSR1_FLAG_MATH_EXACT)) && !a.color.stages && !origin_x && !origin_y) {
     const int fp_h32 = footprint_extent(out->height, 2 * kTileH, 0, sy, by);
     const int pitch = easu_lds_pitch(a.fp_w, false, false);
-    if (fp_h32 > 0 && pitch && easu_generic_tall_tiles(out->width, out->height, out->frames, device_cus(), easu_lds_bytes(in->format, pitch, fp_h32)) &&
+    if (fp_h32 > 0 && pitch &&
+        easu_generic_tall_tiles(out->width, out->height, out->frames, device_cus(),
+                                strict ? easu_strict_lds_bytes(in->format, pitch, fp_h32, 2 * kTileH) : easu_lds_bytes(in->format, pitch, fp_h32)) &&
         (long long)(fp_h32 + 1) * a.in.pitch < (1ll << 31)) {
       tall = true;
       a.fp_h = fp_h32;
@@ -396,7 +408,7 @@ static int easu_dispatch_impl(const fsr1_image* in, const fsr1_image* out, const
   } else if (a.color.stages) {
     e = easu_color_launch(a, in->format, out->format, (flags & FSR1_FLAG_MATH_EXACT) != 0, static_cast<hipStream_t>(stream));
   } else {
-    e = easu_launch(a, in->format, (flags & FSR1_FLAG_MATH_EXACT) != 0, s2, tall, static_cast<hipStream_t>(stream));
+    e = easu_launch(a, in->format, (flags & FSR1_FLAG_MATH_EXACT) != 0, s2, tall, static_cast<hipStream_t>(stream), strict);
   }
   if (e != hipSuccess) return hip_fail(e, "easu launch");
   return FSR1_OK;
@@ -430,6 +442,7 @@ static int rcas_dispatch_impl(const fsr1_image* in, const fsr1_image* out, const
   RcasArgs a;
   int rc;
   if ((rc = check_flags(flags))) return rc;
+  flags &= ~(uint32_t)FSR1_FLAG_MATH_STRICT;  // F-strict is EASU's property; RCAS runs the default arithmetic under it (include/fsr1_hip.h)
   if ((rc = check_image(in, "rcas input", &a.in))) return rc;
   if ((rc = check_image(out, "rcas output", &a.out))) return rc;
   if ((rc = check_color(stages, "rcas", &a.color))) return rc;
@@ -509,6 +522,7 @@ static int fused_dispatch_impl(const fsr1_image* in, const fsr1_image* out, cons
     return fail(FSR1_ERR_UNSUPPORTED, "fused: unsupported input/output format pair %d -> %d", in->format, out->format);
   if (in->frames != out->frames) return fail(FSR1_ERR_INVALID_ARGUMENT, "fused: frame counts differ (%d vs %d)", in->frames, out->frames);
   if (overlaps(in, a.in, out, a.out)) return fail(FSR1_ERR_INVALID_ARGUMENT, "fused: input and output overlap");
+  if (flags & FSR1_FLAG_MATH_STRICT) flags = (flags & ~(uint32_t)FSR1_FLAG_MATH_STRICT) | FSR1_FLAG_MATH_EXACT;  // TODO(strict fused kernels)
   const bool packed = (flags & FSR1_FLAG_MATH_PACKED_FP16) != 0;
   if (packed && (in->format != FSR1_FORMAT_RGBA16F || a.color.stages))
     return fail(FSR1_ERR_UNSUPPORTED, "fused: packed-fp16 math needs RGBA16F images and runs without colour stages");
@@ -615,7 +629,7 @@ static int upscale_decide(const char* who, const fsr1_image* in, bool have_inter
                 (double)p->render_height, in->width, in->height);
   int rc;
   if ((rc = check_flags(p->flags))) return rc;
-  plan->math = p->flags & (FSR1_FLAG_MATH_EXACT | FSR1_FLAG_MATH_PACKED_FP16 | FSR1_FLAG_NO_FAST_PATHS);
+  plan->math = p->flags & (FSR1_FLAG_MATH_EXACT | FSR1_FLAG_MATH_PACKED_FP16 | FSR1_FLAG_MATH_STRICT | FSR1_FLAG_NO_FAST_PATHS);
   const uint32_t rcas_opts = p->flags & (FSR1_FLAG_RCAS_DENOISE | FSR1_FLAG_RCAS_PASSTHROUGH_ALPHA);
   plan->out_policy = p->flags & (FSR1_FLAG_OUTPUT_STREAMING | FSR1_FLAG_OUTPUT_CACHED);  // of the pass that writes `out`
   const uint32_t overlap = p->flags & FSR1_FLAG_FRAMES_OVERLAP;  // a scheduling hint: travels with the math bits to every pass

@@ -66,11 +66,16 @@ bool easu_generic_tall_tiles(int width, int height, int frames, int cus, size_t 
 
 // s2: launch the exact-2x variant (the caller has checked con0 and laid the grid out for the shifted tiles); tall: on 64 x 32 tiles
 // (default arithmetic only: the EXACT variant's per-pixel form would spill at the seven-wave register budget with the longer loop).
-hipError_t easu_launch(const EasuArgs& a, int fmt, bool exact, bool s2, bool tall, hipStream_t stream) {
+hipError_t easu_strict_launch(const EasuArgs& a, int fmt, bool s2, bool tall, int pitch, hipStream_t stream);  // fsr1_easu_strict.hip
+
+// strict: F-strict (FSR1_FLAG_MATH_STRICT; the host has routed RGBA32F and `c *= c` launches to EXACT): the default arithmetic's launch
+// shape, decided exactly as for the default arithmetic.
+hipError_t easu_launch(const EasuArgs& a, int fmt, bool exact, bool s2, bool tall, hipStream_t stream, bool strict) {
   const bool hdr = (a.flags & FSR1_FLAG_HDR_SQUARE) != 0;
   int pitch = s2 ? 0 : easu_lds_pitch(a.fp_w, exact, false);
   if (pitch && !tall && easu_lds_bytes(fmt, pitch, a.fp_h) > 40 * 1024) pitch = 0;  // (tall footprints of anisotropic ratios: keep the dense layout's occupancy)
   if (!s2 && tall && !pitch) return hipErrorInvalidValue;  // (the host pairs the 512-thread tile with a pitched layout: easu_generic_tall_tiles)
+  if (strict) return (exact || hdr) ? hipErrorInvalidValue : easu_strict_launch(a, fmt, s2, tall, pitch, stream);
 #define FSR1_LAUNCH_H(F, E, S, P) return hdr ? easu_launch_one<F, E, false, F, S, true, P>(a, stream) : easu_launch_one<F, E, false, F, S, false, P>(a, stream)
 #define FSR1_LAUNCH_T(F, E) return hdr ? easu_launch_one<F, E, false, F, true, true, 0, 32>(a, stream) : easu_launch_one<F, E, false, F, true, false, 0, 32>(a, stream)
 #define FSR1_LAUNCH_G8(F, P) return hdr ? easu_launch_one<F, false, false, F, false, true, P, 32, 8>(a, stream) : easu_launch_one<F, false, false, F, false, false, P, 32, 8>(a, stream)

@@ -29,11 +29,17 @@ int easu_lds_pitch(int fp_w, bool exact, bool color);
 // workgroups; 1.3x: 30 KB, 5) and loses 2-2.5 % per workgroup it cannot hold (profiles/ab_r05/r5c6_ab_ldspad.log).  A 64 x 32 tile shares
 // its four apron rows between twice as many pixels — 40 KB for EIGHT waves at 1.5x, four workgroups = 8 waves per SIMD — and stages
 // a fifth less per pixel.  (The same tile with four waves, round 4, halved the waves per CU instead and lost.)
-template <int FMT, bool EXACT, bool COLOR = false, int FOUT = FMT, bool S2 = false, bool HDR = false, int PITCH = 0, int TH = kTileH, int WAVES = 4>
+// STRICT (F-strict, FSR1_FLAG_MATH_STRICT; plain pass, default arithmetic): the default arithmetic's pixels are tested against the
+// store conversion's rounding boundaries, the ones that fail are queued in LDS and re-evaluated in the reference's operation order after
+// the tile's default pass — the stored image is bit-identical to EXACT's (fsr1_device_easu.hpp, "F-strict").  The queue sits behind the
+// footprint region (easu_strict_lds_bytes).
+template <int FMT, bool EXACT, bool COLOR = false, int FOUT = FMT, bool S2 = false, bool HDR = false, int PITCH = 0, int TH = kTileH, int WAVES = 4, bool STRICT = false>
 // amdgpu_waves_per_eu(7, 8): at least seven waves per SIMD, i.e. at most 72 VGPRs.  Only the exact-2x default-arithmetic
 // variant is affected — its row-pair form would take 85 (five waves: 43.7 us) where 68 cost it nothing (41.6 us); every other
 // variant needs fewer than 64 anyway.
-__global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(7, 8))) easu_kernel(const EasuArgs a) {
+// (F-strict on 64 x 32 exact-2x tiles: footprint + queue = 26.4 KB, six workgroups per CU — and six waves per SIMD's 80 registers, which its
+//  re-evaluation loop beside the two-step pixel loop needs)
+__global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(STRICT && S2 && TH == 32 ? 6 : 7, 8))) easu_kernel(const EasuArgs a) {
   typedef typename Pixel<FOUT>::T texel_t;
   static_assert(TH % 16 == 0, "a wave filters two quad rows per 16 tile rows");
   static_assert(WAVES == 4 || (WAVES == 8 && TH == 32 && !S2), "eight waves: the generic kernel's 64 x 32 tile");
@@ -43,7 +49,11 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
   constexpr int kS2W = kTileW / 2 + 3, kS2H = kTileH / 2 + 3;  // footprint of every exact-2x tile
   extern __shared__ __attribute__((aligned(16))) char smem[];
   static_assert(!(S2 && PITCH), "the exact-2x variant has a compile-time footprint of its own");
+  static_assert(!STRICT || (!EXACT && !COLOR && !HDR && FOUT == FMT), "F-strict: the plain pass's default arithmetic");
   EasuLds l = PITCH ? easu_lds_carve_pitched<PITCH ? PITCH : 1>(smem) : easu_lds_carve(smem, kS2 ? kS2W * kS2H : a.fp_w * a.fp_h);
+  // (STRICT) the queue behind the footprint region; the counter is zeroed here: the staging's barriers order it before the first push
+  const EasuStrictQueue sq = easu_strict_queue_carve(smem + easu_lds_region_bytes(kS2 ? (size_t)kS2W * kS2H : (PITCH ? (size_t)PITCH * a.fp_h : (size_t)a.fp_w * a.fp_h)));
+  if constexpr (STRICT) easu_strict_queue_reset(sq, threadIdx.x);
 
   const int tiles_per_frame = a.tiles_x * a.tiles_y;
   const int t = xcd_swizzle(blockIdx.x, tiles_per_frame * a.frames);
@@ -61,10 +71,11 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
     const int ox0 = tx * kTileW - 1, oy0 = ty * kTileH - 1;
     const int fx0 = tx * (kTileW / 2) - 2 + (a.origin_x >> 1), fy0 = ty * (kTileH / 2) - 2 + (a.origin_y >> 1);  // (band origins are even here)
     l.fw = kS2W;
-    easu_stage_footprint<FMT, false, EXACT, kS2W, kS2H>(l, a.in, in_frame, fx0, fy0, kS2W, kS2H, tid);
+    easu_stage_footprint<FMT, false, EXACT, kS2W, kS2H, 256, 0, STRICT>(l, a.in, in_frame, fx0, fy0, kS2W, kS2H, tid);
     const int W = a.out.width, H = a.out.height;
     constexpr bool hdr = HDR;
     const bool stream = (a.flags & FSR1_FLAG_OUTPUT_STREAMING) != 0;
+    uint32_t redo_all = 0;  // (F-strict) bit 4 k + b: pixel b (= x + 2 y) of this lane's quad of pass k has to be re-evaluated
 #pragma unroll 1
     for (int k = 0; k < kTileH / 16; ++k) {
       const int qx = lane & 31, qy = (kTileH / 8) * wave + 2 * k + (lane >> 5);
@@ -73,6 +84,29 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
       if (!((xin0 || xin1) && (yin0 || yin1))) continue;
       const int f_idx = (qy + 1) * kS2W + (qx + 1);
       char* const o0 = a.out.base + (long long)frame * a.out.frame_stride + (long long)oya * a.out.pitch + (long long)oxa * (long long)sizeof(texel_t);
+      if constexpr (STRICT) {
+        // F-strict: the default arithmetic's row pairs with the rounding-boundary test; bit b of `redo` = pixel b of the quad (x + 2 y)
+        if (xin0 && xin1 && yin0 && yin1) {
+          const float4_t A[4] = {l.ana[f_idx], l.ana[f_idx + 1], l.ana[f_idx + kS2W], l.ana[f_idx + kS2W + 1]};
+          const float e1 = easu_strict_eps(A[0], A[1], A[2], A[3]);
+          EasuBounds m;
+          rgbf_t q00, q10, q01, q11;
+          texel_t p00, p10, p01, p11;
+          easu_quad_row<true>(l, f_idx, 0.25f, A, m, q00, q10);
+          const EasuStrictEps e = easu_strict_eps_rgb(m, e1);
+          uint32_t redo = easu_strict_resolve<FMT>(m, q00, e, p00) ? 1u : 0u;
+          redo |= easu_strict_resolve<FMT>(m, q10, e, p10) ? 2u : 0u;
+          store_out<sizeof(texel_t)>(o0, TexelPair<FOUT>::make(p00, p10), stream);
+          easu_quad_row<false>(l, f_idx, 0.75f, A, m, q01, q11);
+          redo |= easu_strict_resolve<FMT>(m, q01, e, p01) ? 4u : 0u;
+          redo |= easu_strict_resolve<FMT>(m, q11, e, p11) ? 8u : 0u;
+          store_out<sizeof(texel_t)>(o0 + a.out.pitch, TexelPair<FOUT>::make(p01, p11), stream);
+          redo_all |= redo << (4 * k);
+        } else {  // (border quads) straight to the queue
+          redo_all |= ((xin0 && yin0 ? 1u : 0u) | (xin1 && yin0 ? 2u : 0u) | (xin0 && yin1 ? 4u : 0u) | (xin1 && yin1 ? 8u : 0u)) << (4 * k);
+        }
+        continue;
+      }
       if constexpr (!EXACT) {
         // default arithmetic: a quad is filtered as two ROW PAIRS — the two pixels of a row share the 12-tap window, so every
         // texel is read from LDS once per row and used for both (28 instead of 60 ds_read_b128 per quad: the four analyses once
@@ -114,6 +148,18 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
       row(o0, yin0, 0.25f);
       row(o0 + a.out.pitch, yin1, 0.75f);
     }
+    if constexpr (STRICT) {
+      // pixel id: bits 0-1 = position in the quad, 2-3 (one bit at 64 x 16) = pass k, then lane and wave.  The queued pixels are
+      // re-evaluated densely over the workgroup's first lanes, in the reference's operation order
+      easu_strict_rounds<kThreads>(sq, redo_all, tid * (kTileH / 4), easu_strict_queue_capacity(kTileW * kTileH), tid, [&](int id) {
+        const int sub = id & 3, k = (id >> 2) & (kTileH / 16 - 1), t = id / (kTileH / 4);
+        const int qx = t & 31, qy = (kTileH / 8) * (t >> 6) + 2 * k + ((t >> 5) & 1);
+        const int ox = ox0 + 2 * qx + (sub & 1), oy = oy0 + 2 * qy + (sub >> 1);
+        const int f_idx = (qy + 1) * kS2W + (qx + 1);
+        char* const o = a.out.base + (long long)frame * a.out.frame_stride + (long long)oy * a.out.pitch + (long long)ox * (long long)sizeof(texel_t);
+        store_out<sizeof(texel_t)>(o, easu_strict_pixel<FMT>(l, f_idx, (sub & 1) ? 0.75f : 0.25f, (sub >> 1) ? 0.75f : 0.25f), stream);
+      });
+    }
     return;
   }
 
@@ -130,12 +176,14 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
   const int fh = min((int)floorf((float)(oyl + a.origin_y) * c0y + c0w) + 2 - fy0 + 1, a.fp_h);
   if (!PITCH) l.fw = fw;
   const int row_stride = PITCH ? 2 * PITCH : fw;  // LDS records between footprint rows
-  easu_stage_footprint<FMT, COLOR, EXACT, 0, 0, kThreads, PITCH>(l, a.in, in_frame, fx0, fy0, fw, fh, tid, &a.color);
+  easu_stage_footprint<FMT, COLOR, EXACT, 0, 0, kThreads, PITCH, STRICT>(l, a.in, in_frame, fx0, fy0, fw, fh, tid, &a.color);
 
   // ---- phase 3: output pixels; a lane owns a column, a wave kRowsPerWave = 4 rows.  Which column: easu_lane_column — sixteen
   //      consecutive columns per LDS lane group, so that a group's texels stay within sixteen records (no bank conflicts) ----
-  const int ox = ox0 + easu_lane_column(lane);
-  if (ox >= a.out.width) return;
+  const int col = easu_lane_column(lane);
+  const int ox = ox0 + col;
+  const bool col_in = ox < a.out.width;
+  if (!STRICT && !col_in) return;  // (F-strict: every lane stays for the barrier before the queue is drained)
   char* const out_col = a.out.base + (long long)frame * a.out.frame_stride + (size_t)ox * sizeof(texel_t);
   // :324-326 (x part, shared by this lane's rows)
   float ppx = (float)(ox + a.origin_x) * c0x + c0z;
@@ -147,18 +195,27 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
   const bool hdr = COLOR ? (a.flags & FSR1_FLAG_HDR_SQUARE) != 0 : HDR;
   const bool stream = (a.flags & FSR1_FLAG_OUTPUT_STREAMING) != 0;
 
+  uint32_t redo = 0;  // (F-strict) bit r: this lane's pixel of row r has to be re-evaluated
 #pragma unroll 1
   for (int r = 0; r < kRowsPerWave; ++r) {
     const int oy = oy0 + wave * kRowsPerWave + r;
-    if (oy >= a.out.height) break;
+    if (oy >= a.out.height || (STRICT && !col_in)) break;
     float ppy = (float)(oy + a.origin_y) * c0y + c0w;  // :324-326
     const float fpy = floorf(ppy);
     ppy -= fpy;
     const EasuRowTerms yt = easu_row_terms(ppy);
     const int f_idx = ((int)fpy - fy0) * row_stride + lx;
     EasuBounds m;
-    const rgbf_t p = easu_pixel_with_bounds<EXACT>(l, f_idx, ppx, yt, m);
     texel_t* const dst = reinterpret_cast<texel_t*>(out_col + (long long)oy * a.out.pitch);
+    if constexpr (STRICT) {
+      float e;
+      const rgbf_t p = easu_pixel_with_bounds<false>(l, f_idx, ppx, yt, m, &e);
+      texel_t px;
+      redo |= easu_strict_resolve<FMT>(m, p, easu_strict_eps_rgb(m, e), px) ? 1u << r : 0u;
+      store_out<sizeof(texel_t)>(dst, px, stream);
+      continue;
+    }
+    const rgbf_t p = easu_pixel_with_bounds<EXACT>(l, f_idx, ppx, yt, m);
     if constexpr (COLOR) {
       rgbf_t q = easu_clamp<EXACT>(m, p, hdr);
       color_epilogue<EXACT>(a.color, (uint32_t)ox, (uint32_t)oy, q.r, q.g, q.b);
@@ -167,14 +224,29 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
       store_out<sizeof(texel_t)>(dst, easu_resolve<FMT, EXACT>(m, p, hdr), stream);
     }
   }
+  if constexpr (STRICT) {
+    // group = (wave, column): the lane's four rows; pixel id = 4 * group + row.  The queued pixels densely over the workgroup's first
+    // lanes, in the reference's operation order
+    static_assert(S2 || kRowsPerWave == 4, "a group is a lane's four rows");
+    easu_strict_rounds<kThreads>(sq, redo, 4 * (wave * 64 + col), easu_strict_queue_capacity(kTileW * kTileH), tid, [&](int id) {
+      const int qx = ox0 + ((id >> 2) & 63), qy = oy0 + 4 * (id >> 8) + (id & 3);
+      float px = (float)(qx + a.origin_x) * c0x + c0z, py = (float)(qy + a.origin_y) * c0y + c0w;  // :324-326, as above
+      const float fx = floorf(px), fy = floorf(py);
+      px -= fx;
+      py -= fy;
+      const int f_idx = ((int)fy - fy0) * row_stride + ((int)fx - fx0);
+      char* const o = a.out.base + (long long)frame * a.out.frame_stride + (long long)qy * a.out.pitch + (size_t)qx * sizeof(texel_t);
+      store_out<sizeof(texel_t)>(o, easu_strict_pixel<FMT>(l, f_idx, px, py), stream);
+    });
+  }
 }
 
-template <int FMT, bool EXACT, bool COLOR, int FOUT, bool S2 = false, bool HDR = false, int PITCH = 0, int TH = kTileH, int WAVES = 4>
+template <int FMT, bool EXACT, bool COLOR, int FOUT, bool S2 = false, bool HDR = false, int PITCH = 0, int TH = kTileH, int WAVES = 4, bool STRICT = false>
 hipError_t easu_launch_one(const EasuArgs& a, hipStream_t stream) {
   const dim3 grid((unsigned)(a.tiles_x * a.tiles_y * a.frames)), block(64 * WAVES);
-  const size_t lds = easu_lds_bytes(FMT, PITCH ? PITCH : a.fp_w, a.fp_h);
-  if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&easu_kernel<FMT, EXACT, COLOR, FOUT, S2, HDR, PITCH, TH, WAVES>), lds); e != hipSuccess) return e;
-  hipLaunchKernelGGL((easu_kernel<FMT, EXACT, COLOR, FOUT, S2, HDR, PITCH, TH, WAVES>), grid, block, lds, stream, a);
+  const size_t lds = easu_lds_bytes(FMT, PITCH ? PITCH : a.fp_w, a.fp_h) + (STRICT ? easu_strict_queue_bytes((size_t)kTileW * TH) : 0);
+  if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&easu_kernel<FMT, EXACT, COLOR, FOUT, S2, HDR, PITCH, TH, WAVES, STRICT>), lds); e != hipSuccess) return e;
+  hipLaunchKernelGGL((easu_kernel<FMT, EXACT, COLOR, FOUT, S2, HDR, PITCH, TH, WAVES, STRICT>), grid, block, lds, stream, a);
   return hipGetLastError();
 }
 

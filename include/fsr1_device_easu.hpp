@@ -18,6 +18,9 @@ namespace fsr1 {
 // 4-way bank conflicts — but its 4 bytes per texel cost a resident workgroup at 1.3x and the exact-2x kernels ran 1-2 % slower
 // with it: profiles/ab_r03/r3c3_generic_easu_lane_columns_ab.log; phase 2 is a twentieth of the kernel)
 constexpr int kEasuLdsPerTexel = 16 + 16;
+// F-strict (see the end of this file): threshold of the rounding-boundary test in units of 2^-24 x the window's magnitude
+constexpr float kEasuStrictK = 32.0f;
+constexpr float kEasuStrictScale = kEasuStrictK * 0x1p-24f;
 // bytes of the staged footprint (a multiple of 16: whatever a kernel carves behind it stays aligned)
 __host__ __device__ constexpr size_t easu_lds_region_bytes(size_t capacity_texels) { return capacity_texels * kEasuLdsPerTexel; }
 
@@ -64,6 +67,28 @@ __device__ __forceinline__ int easu_lane_column(int lane) {
   return (lane & 32) | c;
 }
 
+// max(|x|, |y|, |z|) of a texel record and a plain three-way maximum, as single v_max3_f32 (operands straight from LDS: see min4_asm)
+__device__ __forceinline__ float absmax3(float4_t t) {
+  float r;
+  asm("v_max3_f32 %0, |%1|, |%2|, |%3|" : "=v"(r) : "v"(t.x), "v"(t.y), "v"(t.z));
+  return r;
+}
+__device__ __forceinline__ float vmax_asm(float a, float b) {
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ float vmin_asm(float a, float b) {
+  float r;
+  asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ float max3_asm(float a, float b, float c) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+
 // FsrEasuSetF's terms for one position of the '+' neighbourhood  a / b c d / e  (ffx_fsr1.h:295-313), before the
 // bilinear weighting: they depend on the input image only, so the tiled form evaluates them once per input texel.
 // Reference order, no contraction.  Returns (dirX, dirY, lenX^2, lenY^2) when EXACT and (dirX, dirY, lenX^2 + lenY^2, 0)
@@ -95,7 +120,10 @@ __device__ __forceinline__ float4_t easu_analysis(float lA, float lB, float lC, 
 // 32-bit lane offset (global_load ... v_off, s[base]: no 64-bit vector arithmetic).
 // THREADS: threads of the workgroup, all of which must make the call (it contains two barriers).
 // PITCH: 0 = dense arrays of fw-texel rows; P = the row-interleaved layout of easu_lds_carve_pitched<P>.
-template <int FMT, bool PRE = false, bool EXACT = false, int FW = 0, int FH = 0, int THREADS = 256, int PITCH = 0>
+// STRICT (default arithmetic only): phase 2 additionally leaves, in the analysis record's fourth component, the largest |R|, |G|, |B| of
+// the texel's '+' neighbourhood — the four records of a pixel (f g j k) then cover exactly its 12 taps: the scale of the F-strict
+// rounding-boundary test (easu_strict_* below).
+template <int FMT, bool PRE = false, bool EXACT = false, int FW = 0, int FH = 0, int THREADS = 256, int PITCH = 0, bool STRICT = false>
 __device__ __forceinline__ void easu_stage_footprint(const EasuLds& l, const ImageView& in, const char* in_frame, int fx0, int fy0,
                                                      int fw_rt, int fh_rt, int tid, const ColorArgs* color = nullptr) {
   typedef typename Pixel<FMT>::T texel_t;
@@ -174,7 +202,17 @@ __device__ __forceinline__ void easu_stage_footprint(const EasuLds& l, const Ima
     const int y = FW ? j / (FW - 2) : (int)(((float)j + 0.5f) * inv_iw);
     const int rs = PITCH ? kRow : fw;  // row stride of the layout
     const int i = (y + 1) * rs + (j - y * iw) + 1;
-    l.ana[i] = easu_analysis<EXACT>(lum[4 * (i - rs)], lum[4 * (i - 1)], lum[4 * i], lum[4 * (i + 1)], lum[4 * (i + rs)]);
+    if constexpr (STRICT) {
+      static_assert(!EXACT, "F-strict stages the default arithmetic's records");
+      // whole records instead of five lumas four dwords apart: the same LDS cycles (the strided ds_read_b32 are served four ways), and
+      // the colours come along for the window magnitude
+      const float4_t tA = l.tex[i - rs], tB = l.tex[i - 1], tC = l.tex[i], tD = l.tex[i + 1], tE = l.tex[i + rs];
+      float4_t an = easu_analysis<false>(tA.w, tB.w, tC.w, tD.w, tE.w);
+      an.w = max3_asm(max3_asm(absmax3(tA), absmax3(tB), absmax3(tC)), absmax3(tD), absmax3(tE));
+      l.ana[i] = an;
+    } else {
+      l.ana[i] = easu_analysis<EXACT>(lum[4 * (i - rs)], lum[4 * (i - 1)], lum[4 * i], lum[4 * (i + 1)], lum[4 * (i + rs)]);
+    }
   }
   __syncthreads();
 }
@@ -384,12 +422,14 @@ __device__ __forceinline__ EasuBounds easu_bounds(const EasuLds& l, int f_idx) {
 // The filter and the dering bounds from ONE pass over the window: f g j k are four of the twelve taps, so the bounds are
 // taken of the tap values as they arrive instead of reading the four texels from LDS a second time (the generic kernels
 // are short of LDS cycles, not of registers).  Same min / max instructions on the same values as easu_bounds(l, f_idx).
+// strict_eps (STRICT staging): receives the F-strict threshold of the pixel (easu_strict_eps of its four analysis records).
 template <bool EXACT>
-__device__ __forceinline__ rgbf_t easu_pixel_with_bounds(const EasuLds& l, int f_idx, float ppx, const EasuRowTerms& yt, EasuBounds& m) {
+__device__ __forceinline__ rgbf_t easu_pixel_with_bounds(const EasuLds& l, int f_idx, float ppx, const EasuRowTerms& yt, EasuBounds& m, float* strict_eps = nullptr) {
   const int fw = l.fw;
   const float4_t* const w0 = l.tex + (f_idx - fw - 1);
   const float4_t* const a0 = w0 + (l.ana - l.tex);
   float4_t cf = {}, cg = {}, cj = {}, ck = {};
+  float mag = 0.0f;
   const rgbf_t p = easu_filter<EXACT>(
       [&](int dx, int dy) {
         const float4_t v = w0[(dy + 1) * fw + (dx + 1)];
@@ -399,8 +439,14 @@ __device__ __forceinline__ rgbf_t easu_pixel_with_bounds(const EasuLds& l, int f
         else if (dy == 1 && dx == 1) ck = v;
         return v;
       },
-      [&](int k) { return a0[((k >> 1) + 1) * fw + (k & 1) + 1]; }, ppx, yt);
+      [&](int k) {
+        const float4_t v = a0[((k >> 1) + 1) * fw + (k & 1) + 1];
+        if (strict_eps) mag = k ? vmax_asm(mag, v.w) : v.w;  // (a null literal at the other call sites: folds away)
+        return v;
+      },
+      ppx, yt);
   m = easu_bounds(cf, cg, cj, ck);
+  if (strict_eps) *strict_eps = kEasuStrictScale * mag;
   return p;
 }
 
@@ -537,6 +583,132 @@ template <int FMT, bool EXACT>
 __device__ __forceinline__ typename Pixel<FMT>::T easu_resolve(const EasuBounds& m, rgbf_t p, bool hdr_square) {
   const rgbf_t q = easu_clamp<EXACT>(m, p, hdr_square);
   return Pixel<FMT>::store(q.r, q.g, q.b, 1.0f);
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// F-strict (FSR1_FLAG_MATH_STRICT): the default arithmetic's speed with FsrEasuF's bits.
+//
+// The default arithmetic's binary32 result differs from the reference order's (EXACT) by a few binary32 ULPs of the WINDOW's
+// magnitude: |default - EXACT| <= 14.6 * 2^-24 * M, M = the largest |R|, |G|, |B| among the pixel's 12 taps, over 1.2e9 values of
+// synthetic, natural, random (uniform, smooth, hard-edged, dark, HDR log-normal) and hostile content at every preset ratio
+// (tools/experiments_r06/measure_scales.py, profiles/ab_r06/r06_scales.json; relative to the VALUE the difference is unbounded: a dark
+// pixel next to bright texels).  The tail falls faster than exponentially (P(> 4) 9e-3, P(> 8) 2e-5, P(> 16) < 1e-9), so with
+//     e = kEasuStrictK * 2^-24 * M,   kEasuStrictK = 32
+// the stored value of the default arithmetic is the stored value of FsrEasuF whenever the store conversion maps [x - e, x + e] to ONE
+// code (rounding is monotone, and the dering clamp — applied to both — only ever moves a value onto a bound both share).  Pixels for
+// which it does not (2-4 % of natural content at RGBA16F) are queued in LDS by the workgroup and re-evaluated in the reference's
+// operation order by the first lanes of the workgroup, densely (easu_strict_pixel), before the tile's footprint leaves the LDS.
+// The conversion is the format's own (Pixel<FMT>::store), so the test is exact for UNORM storage too.
+// ------------------------------------------------------------------------------------------------------------------------------
+
+template <class T> __device__ __forceinline__ bool texel_bits_differ(const T& a, const T& b);
+template <> __device__ __forceinline__ bool texel_bits_differ<half4_t>(const half4_t& a, const half4_t& b) {
+  return __builtin_bit_cast(unsigned long long, a) != __builtin_bit_cast(unsigned long long, b);
+}
+template <> __device__ __forceinline__ bool texel_bits_differ<uint32_t>(const uint32_t& a, const uint32_t& b) { return a != b; }
+template <> __device__ __forceinline__ bool texel_bits_differ<float4_t>(const float4_t& a, const float4_t& b) {
+  return as_u32(a.x) != as_u32(b.x) || as_u32(a.y) != as_u32(b.y) || as_u32(a.z) != as_u32(b.z);
+}
+
+// The window magnitude of the pixel whose texels f g j k have the analysis records a0 .. a3 (STRICT staging), times the threshold.
+__device__ __forceinline__ float easu_strict_eps(const float4_t& af, const float4_t& ag, const float4_t& aj, const float4_t& ak) {
+  return kEasuStrictScale * vmax_asm(max3_asm(af.w, ag.w, aj.w), ak.w);
+}
+
+// Per-channel thresholds of a pixel (of a quad: the four pixels share their bounds): e, but no more than the width of the dering
+// interval — both arithmetics' results lie in [mn, mx], so they cannot differ by more than mx - mn whatever the window's magnitude.
+// What it buys: a channel that is CONSTANT over f g j k (mn == mx: a black or saturated channel of flat colour, the zero channels of
+// pure primaries) passes the test — both results are that constant — where e alone, scaled by the other channels' magnitude, spans
+// dozens of binary16 steps around zero and would send every such pixel through the re-evaluation.
+struct EasuStrictEps { float r, g, b; };
+__device__ __forceinline__ EasuStrictEps easu_strict_eps_rgb(const EasuBounds& m, float e) {
+  return EasuStrictEps{vmin_asm(e, m.mxR - m.mnR), vmin_asm(e, m.mxG - m.mnG), vmin_asm(e, m.mxB - m.mnB)};
+}
+
+// Dering clamp + store conversion of the default arithmetic's pixel `p`, and the test: true when [x - e, x + e] does not convert to
+// one code in every channel, i.e. the pixel has to be re-evaluated in the reference's operation order.  `out` is the code of x - e:
+// the code of x + e as well when the test passes, overwritten otherwise.
+template <int FMT>
+__device__ __forceinline__ bool easu_strict_resolve(const EasuBounds& m, rgbf_t p, const EasuStrictEps& e, typename Pixel<FMT>::T& out) {
+  const rgbf_t q = easu_clamp<false>(m, p, false);
+  out = Pixel<FMT>::store(q.r - e.r, q.g - e.g, q.b - e.b, 1.0f);
+  const typename Pixel<FMT>::T hi = Pixel<FMT>::store(q.r + e.r, q.g + e.g, q.b + e.b, 1.0f);
+  return texel_bits_differ<typename Pixel<FMT>::T>(out, hi);
+}
+
+// FsrEasuF in the reference's operation order for ONE pixel of a footprint staged for the default arithmetic (STRICT staging): the
+// four analyses are re-derived from the lumas of the 12 taps (the tex records' fourth component) exactly as phase 2 of the EXACT
+// kernels derives them — same function, same operands — so the result is bit-identical to easu_kernel<.., EXACT = true>'s.
+template <int FMT>
+__device__ __forceinline__ typename Pixel<FMT>::T easu_strict_pixel(const EasuLds& l, int f_idx, float ppx, float ppy) {
+  const int fw = l.fw;
+  const float4_t* const w0 = l.tex + (f_idx - fw - 1);
+  const float* const lum = reinterpret_cast<const float*>(w0) + 3;  // luma of window texel (dx, dy) at lum[4 * ((dy + 1) * fw + dx + 1)]
+  float4_t cf = {}, cg = {}, cj = {}, ck = {};
+  const rgbf_t p = easu_filter<true>(
+      [&](int dx, int dy) {
+        const float4_t v = w0[(dy + 1) * fw + (dx + 1)];
+        if (dy == 0 && dx == 0) cf = v;
+        else if (dy == 0 && dx == 1) cg = v;
+        else if (dy == 1 && dx == 0) cj = v;
+        else if (dy == 1 && dx == 1) ck = v;
+        return v;
+      },
+      [&](int k) {
+        const int c = ((k >> 1) + 1) * fw + (k & 1) + 1;  // window index of f / g / j / k
+        return easu_analysis<true>(lum[4 * (c - fw)], lum[4 * (c - 1)], lum[4 * c], lum[4 * (c + 1)], lum[4 * (c + fw)]);
+      },
+      ppx, ppy);
+  return easu_resolve<FMT, true>(easu_bounds(cf, cg, cj, ck), p, false);
+}
+
+// The workgroup's queue of pixels to re-evaluate: 16-bit pixel ids (the kernel's own numbering of its tile) behind a counter.  A lane
+// pushes ONCE, after its pixel loop, whatever it has collected (the atomic's wave-level combination is then paid once per wave; a
+// push per loop pass, or a queue of lane groups expanded before the re-evaluation, were both measured slower: the second puts a serial
+// step and a barrier on the workgroup's critical path — profiles/ab_r06).  The queue holds an EIGHTH of the tile's pixels (natural
+// content queues 2-4 %): LDS per workgroup decides how many workgroups a CU holds, and a queue for every pixel of a 64 x 32 tile
+// (4 KB) costs the generic kernel one of its four (1440p -> 4K: +7 % for the queue alone, profiles/ab_r06/r6c1_strict_breakdown.log).
+// What does not fit stays with its lane and is pushed again in the next round (easu_strict_rounds) — content that queues every pixel
+// runs tile_pixels / capacity rounds of fully occupied re-evaluation passes.
+struct EasuStrictQueue {
+  uint32_t* count;      // pushes of this round, may exceed the capacity
+  unsigned short* ids;  // [capacity]
+};
+// (at least 256: four waves' worth per round where the tile is 1024 pixels)
+__host__ __device__ constexpr int easu_strict_queue_capacity(int tile_pixels) { return tile_pixels / 8 < 256 ? 256 : tile_pixels / 8; }
+// bytes of LDS behind the footprint region for a tile of `tile_pixels` pixels
+__host__ __device__ constexpr size_t easu_strict_queue_bytes(size_t tile_pixels) { return 16 + (((size_t)easu_strict_queue_capacity((int)tile_pixels) * 2 + 15) & ~(size_t)15); }
+__device__ __forceinline__ EasuStrictQueue easu_strict_queue_carve(char* p) {
+  return EasuStrictQueue{reinterpret_cast<uint32_t*>(p), reinterpret_cast<unsigned short*>(p + 16)};
+}
+__device__ __forceinline__ void easu_strict_queue_reset(const EasuStrictQueue& q, int tid) {
+  if (tid == 0) *q.count = 0;
+}
+// Appends the pixels whose bits are set in `mask` (bit b = pixel id_base + b), for this lane; returns the bits that found no room.
+__device__ __forceinline__ uint32_t easu_strict_push(const EasuStrictQueue& q, uint32_t mask, int id_base, int capacity) {
+  if (mask) {
+    uint32_t at = atomicAdd(q.count, (uint32_t)__builtin_popcount(mask));
+    while (mask && at < (uint32_t)capacity) {
+      q.ids[at++] = (unsigned short)(id_base + __builtin_ctz(mask));
+      mask &= mask - 1;
+    }
+  }
+  return mask;
+}
+// The re-evaluation rounds.  Every thread of the workgroup calls this once after its pixel loop with the pixels it collected
+// (`mask`, bit b = pixel id_base + b); `redo(id)` re-evaluates and stores pixel `id`.  PRE: the queue was reset before a barrier.
+template <int THREADS, class Redo>
+__device__ __forceinline__ void easu_strict_rounds(const EasuStrictQueue& q, uint32_t mask, int id_base, int capacity, int tid, const Redo& redo) {
+  for (;;) {
+    mask = easu_strict_push(q, mask, id_base, capacity);
+    __syncthreads();
+    const int pushed = (int)*q.count, n = pushed < capacity ? pushed : capacity;
+    for (int i = tid; i < n; i += THREADS) redo((int)q.ids[i]);
+    if (pushed <= capacity) break;  // (workgroup-uniform)
+    __syncthreads();                // everyone has read the count and its ids
+    easu_strict_queue_reset(q, tid);
+    __syncthreads();
+  }
 }
 
 }  // namespace fsr1

@@ -104,6 +104,17 @@ enum {
    * (v_pk_*_f16), parity class "H" (vs the reference's CPU-evaluated H path). */
   FSR1_FLAG_MATH_EXACT = 1u << 4,
   FSR1_FLAG_MATH_PACKED_FP16 = 1u << 5,
+  /* STRICT ("F-strict", round 6): EASU's stored image is BIT-IDENTICAL to FSR1_FLAG_MATH_EXACT's — i.e. to the CPU-evaluated
+   * FsrEasuF rounded to the storage format — at close to the default arithmetic's speed: every pixel is evaluated with the default
+   * arithmetic and tested against the store conversion's rounding boundaries with a margin that covers the default arithmetic's
+   * measured distance from the reference order (|default - EXACT| <= 14.6 x 2^-24 x the 12-tap window's largest |R|,|G|,|B| over
+   * 1.2e9 values of every kind of content; margin 32: include/fsr1_device_easu.hpp); the 2-4 % of pixels that fail the test are
+   * re-evaluated in the reference's operation order inside the same launch.  RCAS (as its own dispatch or as the second half of the
+   * fused launch) runs the DEFAULT arithmetic under this flag — within 1 binary16 ULP of FsrRcasF on identical input — so the final
+   * image of EASU -> RCAS is within 1 ULP of the reference chain FsrEasuF -> RTNE -> FsrRcasF end to end (the default arithmetic:
+   * 99.99 % within 1 ULP, max 6).  RGBA32F storage (no conversion to test against), `c *= c` and colour-stage launches take the EXACT
+   * kernels under this flag.  Exclusive with MATH_EXACT and MATH_PACKED_FP16. */
+  FSR1_FLAG_MATH_STRICT = 1u << 6,
   /* Diagnostics: never pick a shape-specialised kernel (e.g. the exact-2x variants, whose lanes own 2x2 output quads).
    * The specialised kernels run the same per-pixel arithmetic on the same values: results are bit-identical either way
    * (tests assert it); the flag exists so that this can be checked and the gain measured. */

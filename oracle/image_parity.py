@@ -23,6 +23,22 @@ SHAPES = {
 }
 
 
+def natural_frame(width=1477, height=831, x0=0, y0=0, dtype=np.float16):
+    """A (height, width, 4) crop of the natural-content fixture tests/golden/natural_1477x831_rgb8.npz (the top-left corner of
+    the reference's screenshot.png: GUI text, sky gradient, foliage, texture; made by tests/golden/gen_natural.py): 8-bit code
+    / 255 rounded to binary16, alpha = 1 — every value is binary16-representable, so the CPU checker (float32) and the GPU
+    (fp16 storage) read identical inputs."""
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "natural_1477x831_rgb8.npz")
+    rgb = np.load(path)["rgb8"]
+    if x0 < 0 or y0 < 0 or x0 + width > rgb.shape[1] or y0 + height > rgb.shape[0]:
+        raise ValueError("crop %dx%d at (%d, %d) leaves the %dx%d fixture" % (width, height, x0, y0, rgb.shape[1], rgb.shape[0]))
+    img = np.ones((height, width, 4), np.float32)
+    img[..., :3] = rgb[y0:y0 + height, x0:x0 + width, :].astype(np.float32) / np.float32(255.0)
+    h16 = img.astype(np.float16)
+    return h16 if dtype == np.float16 else h16.astype(dtype)
+
+
 def checker():
     import cpu_oracle
     return cpu_oracle.ref() if cpu_oracle.have_ref() else cpu_oracle.port()

@@ -33,16 +33,22 @@ def test_no_kernel_spills_or_uses_scratch(meta):
 
 @pytest.mark.parametrize("kernel,max_vgpr", [
     # the headline's kernels: exact-2x EASU (row-pair form) at seven waves, RCAS with the 2-row ring at eight
-    ("fsr1::easu_kernel<0, false, false, 0, true, false, 0, 16, 4>", 72),
-    ("fsr1::easu_kernel<0, false, false, 0, true, false, 0, 32, 4>", 72),  # the 64 x 32 tile of large / overlapped launches
+    ("fsr1::easu_kernel<0, false, false, 0, true, false, 0, 16, 4, false>", 72),
+    ("fsr1::easu_kernel<0, false, false, 0, true, false, 0, 32, 4, false>", 72),  # the 64 x 32 tile of large / overlapped launches
     ("fsr1::rcas_kernel<0, false, false, false, 0, 2>", 64),
     # EXACT exact-2x EASU with the quad's analyses shared: seven waves
-    ("fsr1::easu_kernel<0, true, false, 0, true, false, 0, 16, 4>", 72),
+    ("fsr1::easu_kernel<0, true, false, 0, true, false, 0, 16, 4, false>", 72),
     # generic EASU (pitched layout): eight waves
-    ("fsr1::easu_kernel<0, false, false, 0, false, false, 48, 16, 4>", 64),
+    ("fsr1::easu_kernel<0, false, false, 0, false, false, 48, 16, 4, false>", 64),
     # ... and its 512-thread form on 64 x 32 tiles (round 5): four workgroups of eight waves per CU = eight waves per SIMD
-    ("fsr1::easu_kernel<0, false, false, 0, false, false, 48, 32, 8>", 64),
-    ("fsr1::easu_kernel<0, false, false, 0, false, false, 56, 32, 8>", 64),
+    ("fsr1::easu_kernel<0, false, false, 0, false, false, 48, 32, 8, false>", 64),
+    ("fsr1::easu_kernel<0, false, false, 0, false, false, 56, 32, 8, false>", 64),
+    # F-strict (round 6): the default arithmetic + the rounding-boundary test + the in-workgroup re-evaluation in the reference's order.
+    # 64 x 16 exact-2x tiles at seven waves; 64 x 32 at six (26.4 KB of LDS: six workgroups per CU anyway); generic at eight
+    ("fsr1::easu_kernel<0, false, false, 0, true, false, 0, 16, 4, true>", 72),
+    ("fsr1::easu_kernel<0, false, false, 0, true, false, 0, 32, 4, true>", 80),
+    ("fsr1::easu_kernel<0, false, false, 0, false, false, 48, 32, 8, true>", 64),
+    ("fsr1::easu_kernel<0, false, false, 0, false, false, 56, 32, 8, true>", 64),
     # fused exact-2x launch, one-step and walking form: seven workgroups per CU is what their LDS admits
     ("fsr1::fused_s2_kernel<0, false, false, 4>", 72),
     ("fsr1::fused_s2_kernel<0, false, true, 4>", 72),
