@@ -20,11 +20,13 @@ int easu_lds_pitch(int fp_w, bool exact, bool color);
 size_t easu_lds_bytes(int fmt, int fp_w, int fp_h);
 hipError_t rcas_launch(const RcasArgs& a, int fmt, bool exact, hipStream_t stream);
 void rcas_geometry(int width, int height, int frames, bool overlapped, int* tiles_x, int* tiles_y, int* rows);
-hipError_t fused_launch(const FusedArgs& a, int fmt, bool exact, hipStream_t stream);
+hipError_t fused_launch(const FusedArgs& a, int fmt, bool exact, hipStream_t stream, bool strict);
+size_t fused_strict_lds_bytes(int fmt, int fp_w, int fp_h);
 size_t fused_lds_bytes(int fmt, int fp_w, int fp_h);
 hipError_t fused_h_launch(const FusedArgs& a, hipStream_t stream);
-hipError_t fused_s2_launch(const FusedArgs& a, int fmt, bool exact, bool tall, hipStream_t stream);
+hipError_t fused_s2_launch(const FusedArgs& a, int fmt, bool exact, bool tall, hipStream_t stream, bool strict);
 size_t fused_s2_lds_bytes(int fmt, int waves);
+size_t fused_s2_strict_lds_bytes(int fmt, int waves);
 bool fused_s2_tall_tiles(int width, int height, int frames, int steps, int cus, int fmt);
 void fused_s2_geometry(int width, int height, int steps, int* tiles_x, int* tiles_y, int step_rows);
 int fused_s2_run_steps(int width, int height, int frames, int cus, int wgs_per_cu, bool overlapped);
@@ -442,7 +444,11 @@ static int rcas_dispatch_impl(const fsr1_image* in, const fsr1_image* out, const
   RcasArgs a;
   int rc;
   if ((rc = check_flags(flags))) return rc;
-  flags &= ~(uint32_t)FSR1_FLAG_MATH_STRICT;  // F-strict is EASU's property; RCAS runs the default arithmetic under it (include/fsr1_hip.h)
+  // F-strict is EASU's property: RCAS runs the default arithmetic under it — except where EASU has no strict variant and runs EXACT
+  // (RGBA32F storage, colour stages): then RCAS does too, so that the fused launch, which cannot mix arithmetics there, stays
+  // bit-identical to the two dispatches (include/fsr1_hip.h)
+  if (flags & FSR1_FLAG_MATH_STRICT)
+    flags = (flags & ~(uint32_t)FSR1_FLAG_MATH_STRICT) | ((in && (in->format == FSR1_FORMAT_RGBA32F || (stages && stages->stages))) ? (uint32_t)FSR1_FLAG_MATH_EXACT : 0u);
   if ((rc = check_image(in, "rcas input", &a.in))) return rc;
   if ((rc = check_image(out, "rcas output", &a.out))) return rc;
   if ((rc = check_color(stages, "rcas", &a.color))) return rc;
@@ -522,7 +528,10 @@ static int fused_dispatch_impl(const fsr1_image* in, const fsr1_image* out, cons
     return fail(FSR1_ERR_UNSUPPORTED, "fused: unsupported input/output format pair %d -> %d", in->format, out->format);
   if (in->frames != out->frames) return fail(FSR1_ERR_INVALID_ARGUMENT, "fused: frame counts differ (%d vs %d)", in->frames, out->frames);
   if (overlaps(in, a.in, out, a.out)) return fail(FSR1_ERR_INVALID_ARGUMENT, "fused: input and output overlap");
-  if (flags & FSR1_FLAG_MATH_STRICT) flags = (flags & ~(uint32_t)FSR1_FLAG_MATH_STRICT) | FSR1_FLAG_MATH_EXACT;  // TODO(strict fused kernels)
+  // F-strict: EASU's half bit-identical to EXACT's, RCAS's half in the default arithmetic.  Where EASU has no strict variant (RGBA32F:
+  // no store conversion to test against; colour stages) BOTH halves run EXACT, as the two dispatches do under the flag
+  if ((flags & FSR1_FLAG_MATH_STRICT) && (in->format == FSR1_FORMAT_RGBA32F || a.color.stages))
+    flags = (flags & ~(uint32_t)FSR1_FLAG_MATH_STRICT) | FSR1_FLAG_MATH_EXACT;
   const bool packed = (flags & FSR1_FLAG_MATH_PACKED_FP16) != 0;
   if (packed && (in->format != FSR1_FORMAT_RGBA16F || a.color.stages))
     return fail(FSR1_ERR_UNSUPPORTED, "fused: packed-fp16 math needs RGBA16F images and runs without colour stages");
@@ -539,7 +548,8 @@ static int fused_dispatch_impl(const fsr1_image* in, const fsr1_image* out, cons
   a.rows_above = rows_above;
   a.rows_below = rows_below;
   if (a.fp_w < 0 || a.fp_h < 0) return fail(FSR1_ERR_INVALID_ARGUMENT, "fused: scale constants con0.xy = (%g, %g) are not usable", sx, sy);
-  if ((packed ? fused_h_lds_bytes(a.fp_w, a.fp_h) : fused_lds_bytes(in->format, a.fp_w, a.fp_h)) > 160 * 1024)
+  const bool strict = (flags & FSR1_FLAG_MATH_STRICT) != 0;
+  if ((packed ? fused_h_lds_bytes(a.fp_w, a.fp_h) : strict ? fused_strict_lds_bytes(in->format, a.fp_w, a.fp_h) : fused_lds_bytes(in->format, a.fp_w, a.fp_h)) > 160 * 1024)
     return fail(FSR1_ERR_UNSUPPORTED, "fused: input/output ratio (%g, %g) needs more LDS than a CU has", sx, sy);
   if ((long long)(a.fp_h + 1) * a.in.pitch >= (1ll << 31))
     return fail(FSR1_ERR_UNSUPPORTED, "fused: input row pitch %lld too large for a %d-row footprint", a.in.pitch, a.fp_h);
@@ -560,8 +570,8 @@ static int fused_dispatch_impl(const fsr1_image* in, const fsr1_image* out, cons
   const bool exact = (flags & FSR1_FLAG_MATH_EXACT) != 0;
   hipError_t e = packed ? (s2 ? fused_s2_h_launch(a, static_cast<hipStream_t>(stream)) : fused_h_launch(a, static_cast<hipStream_t>(stream)))
                  : a.color.stages ? fused_color_launch(a, in->format, out->format, exact, static_cast<hipStream_t>(stream))
-                 : s2             ? fused_s2_launch(a, in->format, exact, tall, static_cast<hipStream_t>(stream))
-                                  : fused_launch(a, in->format, exact, static_cast<hipStream_t>(stream));
+                 : s2             ? fused_s2_launch(a, in->format, exact, tall, static_cast<hipStream_t>(stream), strict)
+                                  : fused_launch(a, in->format, exact, static_cast<hipStream_t>(stream), strict);
   if (e != hipSuccess) return hip_fail(e, "fused launch");
   return FSR1_OK;
 }

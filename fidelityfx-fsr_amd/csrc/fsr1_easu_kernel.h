@@ -151,7 +151,7 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
     if constexpr (STRICT) {
       // pixel id: bits 0-1 = position in the quad, 2-3 (one bit at 64 x 16) = pass k, then lane and wave.  The queued pixels are
       // re-evaluated densely over the workgroup's first lanes, in the reference's operation order
-      easu_strict_rounds<kThreads>(sq, redo_all, tid * (kTileH / 4), easu_strict_queue_capacity(kTileW * kTileH), tid, [&](int id) {
+      easu_strict_rounds<kThreads>(sq, redo_all, [&](int b) { return tid * (kTileH / 4) + b; }, easu_strict_queue_capacity(kTileW * kTileH), tid, [&](int id) {
         const int sub = id & 3, k = (id >> 2) & (kTileH / 16 - 1), t = id / (kTileH / 4);
         const int qx = t & 31, qy = (kTileH / 8) * (t >> 6) + 2 * k + ((t >> 5) & 1);
         const int ox = ox0 + 2 * qx + (sub & 1), oy = oy0 + 2 * qy + (sub >> 1);
@@ -228,7 +228,7 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
     // group = (wave, column): the lane's four rows; pixel id = 4 * group + row.  The queued pixels densely over the workgroup's first
     // lanes, in the reference's operation order
     static_assert(S2 || kRowsPerWave == 4, "a group is a lane's four rows");
-    easu_strict_rounds<kThreads>(sq, redo, 4 * (wave * 64 + col), easu_strict_queue_capacity(kTileW * kTileH), tid, [&](int id) {
+    easu_strict_rounds<kThreads>(sq, redo, [&](int b) { return 4 * (wave * 64 + col) + b; }, easu_strict_queue_capacity(kTileW * kTileH), tid, [&](int id) {
       const int qx = ox0 + ((id >> 2) & 63), qy = oy0 + 4 * (id >> 8) + (id & 3);
       float px = (float)(qx + a.origin_x) * c0x + c0z, py = (float)(qy + a.origin_y) * c0y + c0w;  // :324-326, as above
       const float fx = floorf(px), fy = floorf(py);

@@ -19,7 +19,20 @@ size_t fused_lds_bytes(int fmt, int fp_w, int fp_h) {
   return easu_lds_region_bytes((size_t)fp_w * fp_h) + (size_t)kMidW * kMidH * texel;  // footprint + the intermediate tile
 }
 
-hipError_t fused_launch(const FusedArgs& a, int fmt, bool exact, hipStream_t stream) {
+// F-strict: + the queue of the apron tile's pixels behind the intermediate tile (its size rounded up to 16 bytes)
+size_t fused_strict_lds_bytes(int fmt, int fp_w, int fp_h) { return ((fused_lds_bytes(fmt, fp_w, fp_h) + 15) & ~(size_t)15) + easu_strict_queue_bytes((size_t)kMidW * kMidH); }
+
+// strict: F-strict (the host has routed RGBA32F to EXACT)
+hipError_t fused_launch(const FusedArgs& a, int fmt, bool exact, hipStream_t stream, bool strict) {
+  if (strict) {
+    if (exact) return hipErrorInvalidValue;
+    switch (fmt) {
+      case FSR1_FORMAT_RGBA16F: return fused_launch_one<FSR1_FORMAT_RGBA16F, false, false, FSR1_FORMAT_RGBA16F, true>(a, stream);
+      case FSR1_FORMAT_RGBA8_UNORM: return fused_launch_one<FSR1_FORMAT_RGBA8_UNORM, false, false, FSR1_FORMAT_RGBA8_UNORM, true>(a, stream);
+      case FSR1_FORMAT_R10G10B10A2_UNORM: return fused_launch_one<FSR1_FORMAT_R10G10B10A2_UNORM, false, false, FSR1_FORMAT_R10G10B10A2_UNORM, true>(a, stream);
+      default: return hipErrorInvalidValue;
+    }
+  }
 #define FSR1_LAUNCH_E(F) return exact ? fused_launch_one<F, true, false, F>(a, stream) : fused_launch_one<F, false, false, F>(a, stream)
   switch (fmt) {
     case FSR1_FORMAT_RGBA16F: FSR1_LAUNCH_E(FSR1_FORMAT_RGBA16F);

@@ -15,7 +15,10 @@ constexpr int kMidH = kFusedTileH + 2;
 // COLOR: colour stages fused in (fsr1_device_color.hpp) — FsrSrtmF on every input texel as it is loaded (prologue of
 // EASU), FsrLfgaF / FsrSrtmInvF / FsrTepdC*F on the RCAS result before it is stored as FOUT.  The EASU->RCAS
 // intermediary in LDS keeps the input's format FMT.  COLOR = false is the plain kernel (FOUT == FMT).
-template <int FMT, bool EXACT, bool COLOR = false, int FOUT = FMT>
+// STRICT (F-strict; plain kernel, default arithmetic): the apron tile's EASU pixels are tested against the store conversion's rounding
+// boundaries and the ones that fail re-evaluated in the reference's operation order into the LDS tile before RCAS reads it; the RCAS half
+// runs the default arithmetic (include/fsr1_hip.h, FSR1_FLAG_MATH_STRICT).  The queue sits behind the tile (fused_strict_lds_bytes).
+template <int FMT, bool EXACT, bool COLOR = false, int FOUT = FMT, bool STRICT = false>
 __global__ void __launch_bounds__(kThreads) fused_kernel(const FusedArgs a) {
   typedef typename Pixel<FMT>::T texel_t;
   typedef typename Pixel<FOUT>::T out_t;
@@ -23,6 +26,9 @@ __global__ void __launch_bounds__(kThreads) fused_kernel(const FusedArgs a) {
   const int cap = a.fp_w * a.fp_h;
   EasuLds l = easu_lds_carve(smem, cap);
   texel_t* const mid = reinterpret_cast<texel_t*>(smem + easu_lds_region_bytes(cap));  // [kMidH][kMidW]
+  static_assert(!STRICT || (!EXACT && !COLOR), "F-strict: the plain kernel's default arithmetic");
+  const EasuStrictQueue sq = easu_strict_queue_carve(reinterpret_cast<char*>(mid) + ((sizeof(texel_t) * kMidW * kMidH + 15) & ~(size_t)15));  // (STRICT)
+  if constexpr (STRICT) easu_strict_queue_reset(sq, threadIdx.x);
 
   const int tiles_per_frame = a.tiles_x * a.tiles_y;
   const int t = xcd_swizzle(blockIdx.x, tiles_per_frame * a.frames);
@@ -46,25 +52,36 @@ __global__ void __launch_bounds__(kThreads) fused_kernel(const FusedArgs a) {
   l.fw = fw;
 
   const int tid = threadIdx.x;
-  easu_stage_footprint<FMT, COLOR, EXACT>(l, a.in, a.in.base + (long long)frame * a.in.frame_stride, fx0, fy0, fw, fh, tid, &a.color);
+  easu_stage_footprint<FMT, COLOR, EXACT, 0, 0, 256, 0, STRICT>(l, a.in, a.in.base + (long long)frame * a.in.frame_stride, fx0, fy0, fw, fh, tid, &a.color);
 
   // ---- phase 3: EASU on the apron tile -> LDS, in the storage format (EASU runs with Sample.x = 0 when
   //      RCAS follows: FSR_Filter.cpp:107).  A lane owns apron column `lane` (its x position math is done once),
   //      the waves share the kMidH rows; the two columns left over (64, 65) are one extra partial pass. ----
   const int lane = tid & 63, wave = tid >> 6;
+  uint32_t redo = 0;  // (F-strict) this lane's pixels to re-evaluate
+  int redo_col = 0;
+  // (returns, F-strict only, whether the pixel has to be re-evaluated)
   auto easu_to_mid = [&](int mx, int my, float ppx, int lxf, bool x_ok) {
     const int oy = oy0 - 1 + my;
     texel_t px = Pixel<FMT>::zero();
+    bool again = false;
     if (x_ok && oy >= ylo && oy <= yhi) {
       float ppy = (float)(oy + yorg) * c0y + c0w;  // :324-326
       const float fpy = floorf(ppy);
       ppy -= fpy;
       const int f_idx = ((int)fpy - fy0) * fw + lxf;
       EasuBounds m;  // taken of the taps as they arrive: no second read of f g j k
-      const rgbf_t p = easu_pixel_with_bounds<EXACT>(l, f_idx, ppx, easu_row_terms(ppy), m);
-      px = easu_resolve<FMT, EXACT>(m, p, false);
+      if constexpr (STRICT) {
+        float e;
+        const rgbf_t p = easu_pixel_with_bounds<false>(l, f_idx, ppx, easu_row_terms(ppy), m, &e);
+        again = easu_strict_resolve<FMT>(m, p, easu_strict_eps_rgb(m, e), px);
+      } else {
+        const rgbf_t p = easu_pixel_with_bounds<EXACT>(l, f_idx, ppx, easu_row_terms(ppy), m);
+        px = easu_resolve<FMT, EXACT>(m, p, false);
+      }
     }
     mid[my * kMidW + mx] = px;
+    return again;
   };
   auto x_position = [&](int mx, float& ppx, int& lxf) {
     const int ox = ox0 - 1 + mx;
@@ -80,17 +97,34 @@ __global__ void __launch_bounds__(kThreads) fused_kernel(const FusedArgs a) {
     const int mx = easu_lane_column(lane);  // sixteen consecutive columns per LDS lane group: no bank conflicts on the window reads
     const bool x_ok = x_position(mx, ppx, lxf);
 #pragma unroll 1
-    for (int my = wave; my < kMidH; my += 4) easu_to_mid(mx, my, ppx, lxf, x_ok);
+    for (int my = wave; my < kMidH; my += 4) redo |= easu_to_mid(mx, my, ppx, lxf, x_ok) ? 1u << (my >> 2) : 0u;
+    redo_col = mx;
   }
   // leftover columns: 2 x kMidH pixels, given to the last wave (it has the fewest rows above when kMidH % 4 == 2)
+  static_assert(2 * kMidH <= 64 && kMidH <= 4 * 7, "one leftover pixel per lane of the last wave; bit 7 of the F-strict mask is free for it");
   if (wave == 3) {
     for (int t = lane; t < 2 * kMidH; t += 64) {
       float ppx;
       int lxf;
       const int mx = kTileW + (t & 1), my = t >> 1;
       const bool x_ok = x_position(mx, ppx, lxf);
-      easu_to_mid(mx, my, ppx, lxf, x_ok);
+      redo |= easu_to_mid(mx, my, ppx, lxf, x_ok) ? 1u << 7 : 0u;
     }
+  }
+  if constexpr (STRICT) {
+    // pixel id = its index in the LDS tile.  Bit b < 7 of a lane's mask: row wave + 4 b of its column; bit 7: the last wave's leftover pixel
+    easu_strict_rounds<kThreads>(
+        sq, redo, [&](int b) { return b == 7 ? (lane >> 1) * kMidW + kTileW + (lane & 1) : (wave + 4 * b) * kMidW + redo_col; },
+        easu_strict_queue_capacity(kMidW * kMidH), tid, [&](int id) {
+          const int my = id / kMidW, mx = id - my * kMidW;
+          float ppx;
+          int lxf;
+          x_position(mx, ppx, lxf);
+          float ppy = (float)(oy0 - 1 + my + yorg) * c0y + c0w;  // :324-326, as in easu_to_mid
+          const float fpy = floorf(ppy);
+          ppy -= fpy;
+          mid[id] = easu_strict_pixel<FMT>(l, ((int)fpy - fy0) * fw + lxf, ppx, ppy);
+        });
   }
   __syncthreads();
 
@@ -127,12 +161,14 @@ __global__ void __launch_bounds__(kThreads) fused_kernel(const FusedArgs a) {
   }
 }
 
-template <int FMT, bool EXACT, bool COLOR, int FOUT>
+size_t fused_strict_lds_bytes(int fmt, int fp_w, int fp_h);
+
+template <int FMT, bool EXACT, bool COLOR, int FOUT, bool STRICT = false>
 hipError_t fused_launch_one(const FusedArgs& a, hipStream_t stream) {
   const dim3 grid((unsigned)(a.tiles_x * a.tiles_y * a.frames)), block(kThreads);
-  const size_t lds = fused_lds_bytes(FMT, a.fp_w, a.fp_h);
-  if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&fused_kernel<FMT, EXACT, COLOR, FOUT>), lds); e != hipSuccess) return e;
-  hipLaunchKernelGGL((fused_kernel<FMT, EXACT, COLOR, FOUT>), grid, block, lds, stream, a);
+  const size_t lds = STRICT ? fused_strict_lds_bytes(FMT, a.fp_w, a.fp_h) : fused_lds_bytes(FMT, a.fp_w, a.fp_h);
+  if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&fused_kernel<FMT, EXACT, COLOR, FOUT, STRICT>), lds); e != hipSuccess) return e;
+  hipLaunchKernelGGL((fused_kernel<FMT, EXACT, COLOR, FOUT, STRICT>), grid, block, lds, stream, a);
   return hipGetLastError();
 }
 

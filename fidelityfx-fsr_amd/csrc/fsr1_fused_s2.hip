@@ -31,6 +31,8 @@ size_t fused_s2_lds_bytes(int fmt, int waves) {
   const size_t texel = fmt == FSR1_FORMAT_RGBA32F ? 16 : (fmt == FSR1_FORMAT_RGBA16F ? 8 : 4);
   return easu_lds_region_bytes((size_t)kFs2FpW * (2 * waves + 3)) + (size_t)kFs2MidW * (4 * waves + 2) * texel;
 }
+// F-strict (FSR1_FLAG_MATH_STRICT): + the queue of a step's EASU pixels behind the ring (fsr1_device_easu.hpp)
+size_t fused_s2_strict_lds_bytes(int fmt, int waves) { return fused_s2_lds_bytes(fmt, waves) + easu_strict_queue_bytes((size_t)kFs2MidW * 4 * waves); }
 
 // Steps per run: one workgroup per (column, run).  With S steps a run wastes 2 of 16 S EASU rows, so S wants to be large; but a
 // launch wants every CU supplied to its end, and a run is S times as long as a tile: measured (profiles/ab_r03/r3c17..r3c19), a
@@ -77,7 +79,10 @@ void fused_s2_geometry(int width, int height, int steps, int* tiles_x, int* tile
 // WAVES: 4 (256 threads, 32 x 8 quads, 16 EASU rows per step) or 8 (512 threads, 32 x 16 quads, 32 rows per step).
 // (register budget: <= 72 VGPRs for seven 4-wave workgroups per CU, which is what their LDS admits; the 8-wave workgroup's LDS admits
 //  three per CU = six waves per SIMD: <= 80)
-template <int FMT, bool EXACT, bool RUN, int WAVES>
+// STRICT (F-strict, default arithmetic only): the step's EASU pixels are tested against the store conversion's rounding boundaries and the
+// ones that fail re-evaluated in the reference's operation order INTO THE RING before the RCAS phase reads it — the EASU half is
+// bit-identical to EXACT's, the RCAS half runs the default arithmetic (include/fsr1_hip.h, FSR1_FLAG_MATH_STRICT).
+template <int FMT, bool EXACT, bool RUN, int WAVES, bool STRICT = false>
 __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(WAVES == 4 ? 7 : 6, 8))) fused_s2_kernel(const FusedArgs a) {
   typedef typename Pixel<FMT>::T texel_t;
   static_assert(WAVES == 4 || WAVES == 8, "a wave filters two quad rows = four EASU rows of a step");
@@ -86,6 +91,8 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
   extern __shared__ __attribute__((aligned(16))) char smem[];
   EasuLds l = easu_lds_carve(smem, kFs2FpW * kFs2FpH);
   texel_t* const mid = reinterpret_cast<texel_t*>(smem + easu_lds_region_bytes(kFs2FpW * kFs2FpH));  // [kFs2Ring][64], a ring of rows
+  static_assert(!STRICT || !EXACT, "F-strict runs the default arithmetic");
+  const EasuStrictQueue sq = easu_strict_queue_carve(reinterpret_cast<char*>(mid + kFs2Ring * kFs2MidW));  // (STRICT)
 
   const int tiles_per_frame = a.tiles_x * a.tiles_y;
   const int t = xcd_swizzle(blockIdx.x, tiles_per_frame * a.frames);
@@ -122,8 +129,9 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
     int tid = threadIdx.x;
     if (RUN) asm volatile("" : "+v"(tid));  // per-lane addresses are re-derived in every step rather than kept in registers across the filter
     const int lane = tid & 63;
-    easu_stage_footprint<FMT, false, EXACT, kFs2FpW, kFs2FpH, kThreads>(l, a.in, in_frame, 31 * tx - 2, ((ay0 + 1) >> 1) - 2 + (a.origin_y >> 1), kFs2FpW,
-                                                                       kFs2FpH, tid);
+    if constexpr (STRICT) easu_strict_queue_reset(sq, tid);  // (the staging's barriers order it before this step's pushes)
+    easu_stage_footprint<FMT, false, EXACT, kFs2FpW, kFs2FpH, kThreads, 0, STRICT>(l, a.in, in_frame, 31 * tx - 2, ((ay0 + 1) >> 1) - 2 + (a.origin_y >> 1),
+                                                                                  kFs2FpW, kFs2FpH, tid);
     // (its two barriers also separate this step's ring writes from the previous step's RCAS reads)
 
     // ---- phase 3: EASU on the step's 64 x 16 pixels, a quad per lane, rounded to the storage format (EASU runs with
@@ -136,7 +144,37 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
       int slot = base + 2 + 2 * qy;  // even, so the quad's two rows never straddle the wrap
       slot -= slot >= kFs2Ring ? kFs2Ring : 0;
       texel_t* const m0 = mid + slot * kFs2MidW + 2 * qx;
-      if (!EXACT && xin0 && xin1 && yin0 && yin1) {  // default arithmetic: two row pairs, every texel read once per row (see easu_kernel)
+      if constexpr (STRICT) {
+        // F-strict: the default arithmetic's row pairs + the rounding-boundary test; the pixels that fail (and the in-image pixels of
+        // the image's border quads) are re-evaluated into the ring below.  Pixel id = 4 * thread + (x + 2 y of the quad)
+        uint32_t redo = 0;
+        if (xin0 && xin1 && yin0 && yin1) {
+          const float4_t A[4] = {l.ana[f_idx], l.ana[f_idx + 1], l.ana[f_idx + kFs2FpW], l.ana[f_idx + kFs2FpW + 1]};
+          const float e1 = easu_strict_eps(A[0], A[1], A[2], A[3]);
+          EasuBounds m;
+          rgbf_t q00, q10, q01, q11;
+          texel_t p00, p10, p01, p11;
+          easu_quad_row<true>(l, f_idx, 0.25f, A, m, q00, q10);
+          const EasuStrictEps e = easu_strict_eps_rgb(m, e1);
+          redo = easu_strict_resolve<FMT>(m, q00, e, p00) ? 1u : 0u;
+          redo |= easu_strict_resolve<FMT>(m, q10, e, p10) ? 2u : 0u;
+          *reinterpret_cast<pair_t*>(m0) = TexelPair<FMT>::make(p00, p10);
+          easu_quad_row<false>(l, f_idx, 0.75f, A, m, q01, q11);
+          redo |= easu_strict_resolve<FMT>(m, q01, e, p01) ? 4u : 0u;
+          redo |= easu_strict_resolve<FMT>(m, q11, e, p11) ? 8u : 0u;
+          *reinterpret_cast<pair_t*>(m0 + kFs2MidW) = TexelPair<FMT>::make(p01, p11);
+        } else {
+          m0[0] = m0[1] = m0[kFs2MidW] = m0[kFs2MidW + 1] = Pixel<FMT>::zero();  // outside the image: 0 (FSR_Pass.hlsl:45,61)
+          redo = (xin0 && yin0 ? 1u : 0u) | (xin1 && yin0 ? 2u : 0u) | (xin0 && yin1 ? 4u : 0u) | (xin1 && yin1 ? 8u : 0u);
+        }
+        easu_strict_rounds<kThreads>(sq, redo, [&](int b) { return 4 * tid + b; }, easu_strict_queue_capacity(kFs2MidW * kFs2Step), tid, [&](int id) {
+          const int sub = id & 3, t = id >> 2, rqx = t & 31, rqy = 2 * (t >> 6) + ((t >> 5) & 1);
+          int rslot = base + 2 + 2 * rqy;
+          rslot -= rslot >= kFs2Ring ? kFs2Ring : 0;
+          mid[(rslot + (sub >> 1)) * kFs2MidW + 2 * rqx + (sub & 1)] =
+              easu_strict_pixel<FMT>(l, (rqy + 1) * kFs2FpW + (rqx + 1), (sub & 1) ? 0.75f : 0.25f, (sub >> 1) ? 0.75f : 0.25f);
+        });
+      } else if (!EXACT && xin0 && xin1 && yin0 && yin1) {  // default arithmetic: two row pairs, every texel read once per row (see easu_kernel)
         const float4_t A[4] = {l.ana[f_idx], l.ana[f_idx + 1], l.ana[f_idx + kFs2FpW], l.ana[f_idx + kFs2FpW + 1]};
         EasuBounds m;
         rgbf_t q00, q10, q01, q11;
@@ -171,6 +209,8 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
     //      neighbouring lanes' centre texels (DPP wave shifts).  Every lane stays active (DPP sources); lanes 0 / 63 and pixels
     //      outside the image store nothing. ----
     {
+      int lane = (int)threadIdx.x & 63;
+      if (STRICT) asm volatile("" : "+v"(lane));  // (nothing per-lane lives across the re-evaluation: re-derived here)
       const int ox = ax0 + lane;
       const bool col_ok = lane >= 1 && lane <= kFs2OutW && ox < W;
       const uint32_t col_off = (uint32_t)ox * (uint32_t)sizeof(texel_t);  // (never used when ox < 0: lane 0 stores nothing)
@@ -206,17 +246,31 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
   }
 }
 
-template <int FMT, bool EXACT, bool RUN, int WAVES>
+template <int FMT, bool EXACT, bool RUN, int WAVES, bool STRICT = false>
 static hipError_t fused_s2_launch_one(const FusedArgs& a, hipStream_t stream) {
   const dim3 grid((unsigned)(a.tiles_x * a.tiles_y * a.frames)), block(64 * WAVES);
-  const size_t lds = fused_s2_lds_bytes(FMT, WAVES);
-  if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&fused_s2_kernel<FMT, EXACT, RUN, WAVES>), lds); e != hipSuccess) return e;
-  hipLaunchKernelGGL((fused_s2_kernel<FMT, EXACT, RUN, WAVES>), grid, block, lds, stream, a);
+  const size_t lds = STRICT ? fused_s2_strict_lds_bytes(FMT, WAVES) : fused_s2_lds_bytes(FMT, WAVES);
+  if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&fused_s2_kernel<FMT, EXACT, RUN, WAVES, STRICT>), lds); e != hipSuccess) return e;
+  hipLaunchKernelGGL((fused_s2_kernel<FMT, EXACT, RUN, WAVES, STRICT>), grid, block, lds, stream, a);
   return hipGetLastError();
 }
 
 // tall: the 512-thread workgroup (one-step launches only: the host pairs it with run_steps == 1)
-hipError_t fused_s2_launch(const FusedArgs& a, int fmt, bool exact, bool tall, hipStream_t stream) {
+// strict: F-strict (the host has routed RGBA32F to EXACT: there is no store conversion to test against)
+hipError_t fused_s2_launch(const FusedArgs& a, int fmt, bool exact, bool tall, hipStream_t stream, bool strict) {
+  if (strict) {
+    if (exact || fmt == FSR1_FORMAT_RGBA32F) return hipErrorInvalidValue;
+#define FSR1_LAUNCH_S(F)                                                         \
+  if (tall) return fused_s2_launch_one<F, false, false, 8, true>(a, stream);     \
+  return a.run_steps > 1 ? fused_s2_launch_one<F, false, true, 4, true>(a, stream) : fused_s2_launch_one<F, false, false, 4, true>(a, stream)
+    switch (fmt) {
+      case FSR1_FORMAT_RGBA16F: FSR1_LAUNCH_S(FSR1_FORMAT_RGBA16F);
+      case FSR1_FORMAT_RGBA8_UNORM: FSR1_LAUNCH_S(FSR1_FORMAT_RGBA8_UNORM);
+      case FSR1_FORMAT_R10G10B10A2_UNORM: FSR1_LAUNCH_S(FSR1_FORMAT_R10G10B10A2_UNORM);
+      default: return hipErrorInvalidValue;
+    }
+#undef FSR1_LAUNCH_S
+  }
 #define FSR1_LAUNCH_E(F)                                                                                                                  \
   if (tall && F != FSR1_FORMAT_RGBA32F)                                                                                                   \
     return exact ? fused_s2_launch_one<F == FSR1_FORMAT_RGBA32F ? FSR1_FORMAT_RGBA16F : F, true, false, 8>(a, stream)                     \

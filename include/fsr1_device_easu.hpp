@@ -644,22 +644,17 @@ __device__ __forceinline__ typename Pixel<FMT>::T easu_strict_pixel(const EasuLd
   const int fw = l.fw;
   const float4_t* const w0 = l.tex + (f_idx - fw - 1);
   const float* const lum = reinterpret_cast<const float*>(w0) + 3;  // luma of window texel (dx, dy) at lum[4 * ((dy + 1) * fw + dx + 1)]
-  float4_t cf = {}, cg = {}, cj = {}, ck = {};
+  // (the bounds first, from reads of their own: taken of the tap values as they arrive they would hold sixteen registers through the
+  //  whole filter, and this function runs beside the callers' loop state at their seven-wave budgets)
+  const EasuBounds m = easu_bounds(l, f_idx);
   const rgbf_t p = easu_filter<true>(
-      [&](int dx, int dy) {
-        const float4_t v = w0[(dy + 1) * fw + (dx + 1)];
-        if (dy == 0 && dx == 0) cf = v;
-        else if (dy == 0 && dx == 1) cg = v;
-        else if (dy == 1 && dx == 0) cj = v;
-        else if (dy == 1 && dx == 1) ck = v;
-        return v;
-      },
+      [&](int dx, int dy) { return w0[(dy + 1) * fw + (dx + 1)]; },
       [&](int k) {
         const int c = ((k >> 1) + 1) * fw + (k & 1) + 1;  // window index of f / g / j / k
         return easu_analysis<true>(lum[4 * (c - fw)], lum[4 * (c - 1)], lum[4 * c], lum[4 * (c + 1)], lum[4 * (c + fw)]);
       },
       ppx, ppy);
-  return easu_resolve<FMT, true>(easu_bounds(cf, cg, cj, ck), p, false);
+  return easu_resolve<FMT, true>(m, p, false);
 }
 
 // The workgroup's queue of pixels to re-evaluate: 16-bit pixel ids (the kernel's own numbering of its tile) behind a counter.  A lane
@@ -684,23 +679,25 @@ __device__ __forceinline__ EasuStrictQueue easu_strict_queue_carve(char* p) {
 __device__ __forceinline__ void easu_strict_queue_reset(const EasuStrictQueue& q, int tid) {
   if (tid == 0) *q.count = 0;
 }
-// Appends the pixels whose bits are set in `mask` (bit b = pixel id_base + b), for this lane; returns the bits that found no room.
-__device__ __forceinline__ uint32_t easu_strict_push(const EasuStrictQueue& q, uint32_t mask, int id_base, int capacity) {
+// Appends the pixels whose bits are set in `mask` (bit b = pixel id_of(b)), for this lane; returns the bits that found no room.
+template <class IdOf>
+__device__ __forceinline__ uint32_t easu_strict_push(const EasuStrictQueue& q, uint32_t mask, const IdOf& id_of, int capacity) {
   if (mask) {
     uint32_t at = atomicAdd(q.count, (uint32_t)__builtin_popcount(mask));
     while (mask && at < (uint32_t)capacity) {
-      q.ids[at++] = (unsigned short)(id_base + __builtin_ctz(mask));
+      q.ids[at++] = (unsigned short)id_of(__builtin_ctz(mask));
       mask &= mask - 1;
     }
   }
   return mask;
 }
 // The re-evaluation rounds.  Every thread of the workgroup calls this once after its pixel loop with the pixels it collected
-// (`mask`, bit b = pixel id_base + b); `redo(id)` re-evaluates and stores pixel `id`.  PRE: the queue was reset before a barrier.
-template <int THREADS, class Redo>
-__device__ __forceinline__ void easu_strict_rounds(const EasuStrictQueue& q, uint32_t mask, int id_base, int capacity, int tid, const Redo& redo) {
+// (`mask`, bit b = pixel id_of(b)); `redo(id)` re-evaluates and stores pixel `id`.  PRE: the queue was reset before a barrier.
+// The first barrier inside also orders the caller's pixel loop before the re-evaluation; none follows the last round.
+template <int THREADS, class IdOf, class Redo>
+__device__ __forceinline__ void easu_strict_rounds(const EasuStrictQueue& q, uint32_t mask, const IdOf& id_of, int capacity, int tid, const Redo& redo) {
   for (;;) {
-    mask = easu_strict_push(q, mask, id_base, capacity);
+    mask = easu_strict_push(q, mask, id_of, capacity);
     __syncthreads();
     const int pushed = (int)*q.count, n = pushed < capacity ? pushed : capacity;
     for (int i = tid; i < n; i += THREADS) redo((int)q.ids[i]);

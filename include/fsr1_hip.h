@@ -112,8 +112,11 @@ enum {
    * re-evaluated in the reference's operation order inside the same launch.  RCAS (as its own dispatch or as the second half of the
    * fused launch) runs the DEFAULT arithmetic under this flag — within 1 binary16 ULP of FsrRcasF on identical input — so the final
    * image of EASU -> RCAS is within 1 ULP of the reference chain FsrEasuF -> RTNE -> FsrRcasF end to end (the default arithmetic:
-   * 99.99 % within 1 ULP, max 6).  RGBA32F storage (no conversion to test against), `c *= c` and colour-stage launches take the EXACT
-   * kernels under this flag.  Exclusive with MATH_EXACT and MATH_PACKED_FP16. */
+   * 99.99 % within 1 ULP, max 6).  Every pipeline (two dispatches, fused launch, fsr1_upscale, fsr1_pipeline) produces the same bits
+   * under this flag.  Where EASU has no strict variant — RGBA32F storage (no conversion to test against), colour stages — EASU and
+   * RCAS both take the EXACT kernels under this flag; an EASU-only launch with `c *= c` takes the EXACT kernel.  Content whose every
+   * window mixes magnitudes (HDR noise) fails the test almost everywhere and runs at about the EXACT kernels' speed.  Exclusive with
+   * MATH_EXACT and MATH_PACKED_FP16. */
   FSR1_FLAG_MATH_STRICT = 1u << 6,
   /* Diagnostics: never pick a shape-specialised kernel (e.g. the exact-2x variants, whose lanes own 2x2 output quads).
    * The specialised kernels run the same per-pixel arithmetic on the same values: results are bit-identical either way

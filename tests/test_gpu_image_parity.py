@@ -10,10 +10,16 @@ reference's true-ratio presets (sample/src/DX12/FSRSample.h:79-95: 1477x831 -> 1
 the two dispatches, the fused launch, `auto`, and frames sent through an fsr1_pipeline.
 
     EXACT    the whole chain is bit-identical (0 differing binary16 values)
-    default  gated on: no NaN, >= 99 % of the R/G/B values within 1 binary16 ULP of the chain; the full histogram
-             (0 / 1 / 2 / 3-4 / > 4 ULP, max, fraction bit-equal) is REPORTED — written to gpurun_out/r05_image_parity.json
-             (committed as profiles/r05_image_parity.json) and quoted in README.md.  Values beyond 1 ULP are where RCAS's
-             limiter (a ratio of small differences) amplifies a 1-ULP difference of the intermediary.
+    STRICT   (FSR1_FLAG_MATH_STRICT, round 6) the intermediary is bit-identical to FsrEasuF, the final image within 1 binary16 ULP of
+             the chain — north_star's tolerance, end to end — for two dispatches, the fused launch, `auto` and pipelined frames
+    default  gated on the class that was MEASURED (round 5: 99.991 % within 1 ULP, 99.965 % bit-equal, max 6): no NaN,
+             >= 99.98 % within 1 ULP, >= 99.95 % bit-equal, max <= 8 ULP; the full histogram (0 / 1 / 2 / 3-4 / > 4 ULP, max, fraction
+             bit-equal) is REPORTED — written to gpurun_out/r06_image_parity.json (committed as profiles/r06_image_parity.json) and
+             quoted in README.md.  Values beyond 1 ULP are where RCAS's limiter (a ratio of small differences) amplifies a 1-ULP
+             difference of the intermediary.
+Round 6 widens the inputs: RCAS sharpness 0 stops (the limiter's gain is largest there, ffx_fsr1.h:654, :756-759) and 1 stop beside the
+sample's 0.25, and NATURAL content — the top-left 1477 x 831 pixels of the reference's own screenshot (tests/golden/gen_natural.py:
+GUI text, a sky gradient, foliage, texture) at exactly 2x and at the 1.3x preset — beside the synthetic generator.
 """
 import importlib
 import json
@@ -28,7 +34,10 @@ torch = pytest.importorskip("torch")
 frames = importlib.import_module("fidelityfx-fsr_amd.frames")
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-MIN_WITHIN_1ULP = 0.99
+MIN_WITHIN_1ULP = 0.9998   # measured 0.99991 .. 0.99993 (profiles/r05_image_parity.json)
+MIN_BIT_EQUAL = 0.9995     # measured 0.99965 .. 0.99966
+MAX_ULP_DEFAULT = 8        # measured 6 at the sample's 0.25 stops
+MAX_ULP_DEFAULT_SHARP0 = 16  # measured 9 at 0 stops: the limiter's gain on a 1-ULP intermediary difference is largest there (round 6)
 REPORT = {}
 
 
@@ -46,24 +55,41 @@ def write_report():
     out_dir = os.path.join(ROOT, "gpurun_out")
     try:
         os.makedirs(out_dir, exist_ok=True)
-        with open(os.path.join(out_dir, "r05_image_parity.json"), "w") as f:
+        with open(os.path.join(out_dir, "r06_image_parity.json"), "w") as f:
             json.dump(REPORT, f, indent=1, sort_keys=True)
     except OSError:
         pass
 
 
 SHAPE_NAMES = ["540p_to_1080p", "1080p_to_4k", "1440p_to_4k", "4k_to_8k", "831p_to_1080p", "1270p_to_4k", "1662p_to_4k"]
+# (case id, content, input extent or shape name, output extent, RCAS sharpness in stops)
+CASES = [(n, "synthetic", n, None, 0.25) for n in SHAPE_NAMES] + [
+    ("1080p_to_4k_sharp0", "synthetic", "1080p_to_4k", None, 0.0),
+    ("1080p_to_4k_sharp1", "synthetic", "1080p_to_4k", None, 1.0),
+    ("1440p_to_4k_sharp0", "synthetic", "1440p_to_4k", None, 0.0),
+    ("natural_2x", "natural", (1477, 831), (2954, 1662), 0.25),
+    ("natural_2x_sharp0", "natural", (1477, 831), (2954, 1662), 0.0),
+    ("natural_2x_sharp1", "natural", (1477, 831), (2954, 1662), 1.0),
+    ("natural_1p3x", "natural", (1477, 831), (1920, 1080), 0.25),
+    ("natural_1p3x_sharp0", "natural", (1477, 831), (1920, 1080), 0.0),
+    ("natural_crop_1p5x", "natural", (1280, 720), (1920, 1080), 0.25),
+]
 
 
-@pytest.mark.parametrize("name", SHAPE_NAMES)
-def test_final_image_against_the_reference_chain(fsr, parity, name):
-    iw, ih, ow, oh = parity.SHAPES[name]
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_final_image_against_the_reference_chain(fsr, parity, case):
+    name, content, shape, out_size, sharp = case
+    if content == "synthetic":
+        iw, ih, ow, oh = parity.SHAPES[shape]
+        img = frames.synthetic_frame(iw, ih, k=7, dtype=np.float16)
+    else:
+        (iw, ih), (ow, oh) = shape, out_size
+        img = parity.natural_frame(iw, ih, x0=(1477 - iw) // 2, y0=(831 - ih) // 2)
     o = parity.checker()
-    img = frames.synthetic_frame(iw, ih, k=7, dtype=np.float16)
-    want, want_mid = parity.reference_chain(o, img.astype(np.float32), ow, oh, 0.25, return_mid=True)
+    want, want_mid = parity.reference_chain(o, img.astype(np.float32), ow, oh, sharp, return_mid=True)
     src = torch.from_numpy(img).cuda()
     con = fsr.FsrEasuCon(iw, ih, iw, ih, ow, oh)
-    rc = fsr.FsrRcasCon(0.25)
+    rc = fsr.FsrRcasCon(sharp)
     mid = torch.zeros(oh, ow, 4, dtype=torch.float16, device="cuda")
 
     def two_pass(flags):
@@ -81,43 +107,49 @@ def test_final_image_against_the_reference_chain(fsr, parity, name):
         pipe = fsr.Pipeline(3)
         dsts = [torch.zeros_like(mid) for _ in range(3)]  # three frames in flight, one per slot; the same input: the outputs must agree
         for d in dsts:
-            pipe.upscale(src, d, sharpness=0.25, use_rcas=True, fused=mode, flags=flags)
+            pipe.upscale(src, d, sharpness=sharp, use_rcas=True, fused=mode, flags=flags)
         pipe.synchronize()
         pipe.close()
         for d in dsts[1:]:
             assert torch.equal(d.view(torch.int16), dsts[0].view(torch.int16)), "%s: frames of one pipeline differ" % name
         return dsts[0]
 
-    entry = {"shape": "%dx%d -> %dx%d" % (iw, ih, ow, oh), "checker": o.kind,
-             "reference": "FsrEasuF -> RTNE binary16 -> FsrRcasF (ffx_fsr1.h:315-437, :684-769), sharpness 0.25 stops"}
+    entry = {"shape": "%dx%d -> %dx%d" % (iw, ih, ow, oh), "content": content, "checker": o.kind,
+             "reference": "FsrEasuF -> RTNE binary16 -> FsrRcasF (ffx_fsr1.h:315-437, :684-769), sharpness %g stops" % sharp}
     # EXACT: the chain is bit-identical end to end
     ex = parity.ulp_histogram(two_pass(fsr.FLAG_MATH_EXACT), want)
     entry["exact_two_dispatch"] = ex
     assert ex["max_ulp"] == 0 and ex["nan_in_output"] == 0 and ex["alpha_equal"], "%s EXACT: the final image differs from the reference chain: %s" % (name, ex)
     ex_mid = parity.ulp_histogram(mid, want_mid)
     assert ex_mid["max_ulp"] == 0, "%s EXACT: the intermediary differs from FsrEasuF: %s" % (name, ex_mid)
-    # default arithmetic: every way the product can run the frame
-    results = {
-        "two_dispatch": two_pass(0),
-        "fused": fused(0),
-        "pipelined_two_dispatch": pipelined(0, 0),
-        "pipelined_auto": pipelined(0, 2),
-    }
-    for how, img_out in results.items():
-        h = parity.ulp_histogram(img_out, want)
-        entry["default_" + how] = h
-        assert h["nan_in_output"] == 0, "%s default %s: NaN in the output" % (name, how)
-        assert h["alpha_equal"], "%s default %s: alpha differs" % (name, how)
-        assert h["frac_within_1ulp"] >= MIN_WITHIN_1ULP, "%s default %s: only %.4f of the values within 1 ULP of the reference chain (%s)" % (
-            name, how, h["frac_within_1ulp"], h)
-    # the product's pipelines agree with each other bit for bit (fused == two dispatches == pipelined)
-    base = results["two_dispatch"].view(torch.int16)
-    for how, img_out in results.items():
-        assert torch.equal(img_out.view(torch.int16), base), "%s: default %s differs from the two dispatches" % (name, how)
-    # and the intermediary of the default arithmetic against FsrEasuF alone (the per-stage class, for the same frame)
-    fsr.easu(src, mid, con=con)
-    entry["default_easu_stage"] = parity.ulp_histogram(mid, want_mid)
-    assert entry["default_easu_stage"]["max_ulp"] <= 1
+    # STRICT and the default arithmetic: every way the product can run the frame
+    for tag, fl in (("strict", fsr.FLAG_MATH_STRICT), ("default", 0)):
+        results = {
+            "two_dispatch": two_pass(fl),
+            "fused": fused(fl),
+            "pipelined_two_dispatch": pipelined(fl, 0),
+            "pipelined_auto": pipelined(fl, 2),
+        }
+        for how, img_out in results.items():
+            h = parity.ulp_histogram(img_out, want)
+            entry["%s_%s" % (tag, how)] = h
+            what = "%s %s %s" % (name, tag, how)
+            assert h["nan_in_output"] == 0, what + ": NaN in the output"
+            assert h["alpha_equal"], what + ": alpha differs"
+            if tag == "strict":
+                assert h["max_ulp"] <= 1, "%s: %d binary16 ULP from the reference chain (F-strict promises <= 1): %s" % (what, h["max_ulp"], h)
+            else:
+                worst = MAX_ULP_DEFAULT if sharp >= 0.25 else MAX_ULP_DEFAULT_SHARP0
+                assert h["frac_within_1ulp"] >= MIN_WITHIN_1ULP and h["frac_bit_equal"] >= MIN_BIT_EQUAL and h["max_ulp"] <= worst, (
+                    "%s: outside the measured class (>= %.4f within 1 ULP, >= %.4f bit-equal, max %d): %s" % (what, MIN_WITHIN_1ULP, MIN_BIT_EQUAL, worst, h))
+        # the product's pipelines agree with each other bit for bit (fused == two dispatches == pipelined)
+        base = results["two_dispatch"].view(torch.int16)
+        for how, img_out in results.items():
+            assert torch.equal(img_out.view(torch.int16), base), "%s: %s %s differs from the two dispatches" % (name, tag, how)
+        # and the intermediary against FsrEasuF alone: strict = 0 differing values, default = the per-stage class
+        fsr.easu(src, mid, con=con, flags=fl)
+        entry[tag + "_easu_stage"] = parity.ulp_histogram(mid, want_mid)
+        assert entry[tag + "_easu_stage"]["max_ulp"] <= (0 if tag == "strict" else 1), "%s %s: the intermediary: %s" % (name, tag, entry[tag + "_easu_stage"])
     REPORT[name] = entry
     print("\n%s %s" % (name, json.dumps({k: (v if not isinstance(v, dict) else {kk: v[kk] for kk in ("max_ulp", "frac_bit_equal", "frac_within_1ulp", "hist") if kk in v})
                                          for k, v in entry.items()})))
