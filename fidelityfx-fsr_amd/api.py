@@ -312,11 +312,14 @@ class FSR_Filter:
         self._hdr = False
         self.fused = False
 
-    def OnCreate(self, slowFallback=True, exact=False, fused=False):
+    def OnCreate(self, slowFallback=True, exact=False, fused=False, strict=False):
         """fused: False = EASU + RCAS dispatches, True = the single fused launch, "auto" = whichever is faster for the
-        scale (fsr1_params.fused = 2; the intermediary is still allocated so that either can run)."""
+        scale (fsr1_params.fused = 2; the intermediary is still allocated so that either can run).
+        strict: FSR1_FLAG_MATH_STRICT — EASU bit-identical to FsrEasuF, the final image within 1 binary16 ULP of the reference chain."""
         _lib.load()
-        self._flags = (FLAG_MATH_EXACT if exact else 0) if slowFallback else FLAG_MATH_PACKED_FP16
+        if exact and strict:
+            raise Fsr1Error("exact and strict are exclusive")
+        self._flags = (FLAG_MATH_EXACT if exact else (FLAG_MATH_STRICT if strict else 0)) if slowFallback else FLAG_MATH_PACKED_FP16
         self.fused = fused
         self._created = True
 

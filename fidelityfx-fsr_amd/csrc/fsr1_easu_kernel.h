@@ -51,9 +51,8 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
   static_assert(!(S2 && PITCH), "the exact-2x variant has a compile-time footprint of its own");
   static_assert(!STRICT || (!EXACT && !COLOR && !HDR && FOUT == FMT), "F-strict: the plain pass's default arithmetic");
   EasuLds l = PITCH ? easu_lds_carve_pitched<PITCH ? PITCH : 1>(smem) : easu_lds_carve(smem, kS2 ? kS2W * kS2H : a.fp_w * a.fp_h);
-  // (STRICT) the queue behind the footprint region; the counter is zeroed here: the staging's barriers order it before the first push
+  // (STRICT) the queue behind the footprint region
   const EasuStrictQueue sq = easu_strict_queue_carve(smem + easu_lds_region_bytes(kS2 ? (size_t)kS2W * kS2H : (PITCH ? (size_t)PITCH * a.fp_h : (size_t)a.fp_w * a.fp_h)));
-  if constexpr (STRICT) easu_strict_queue_reset(sq, threadIdx.x);
 
   const int tiles_per_frame = a.tiles_x * a.tiles_y;
   const int t = xcd_swizzle(blockIdx.x, tiles_per_frame * a.frames);
@@ -151,7 +150,7 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
     if constexpr (STRICT) {
       // pixel id: bits 0-1 = position in the quad, 2-3 (one bit at 64 x 16) = pass k, then lane and wave.  The queued pixels are
       // re-evaluated densely over the workgroup's first lanes, in the reference's operation order
-      easu_strict_rounds<kThreads>(sq, redo_all, [&](int b) { return tid * (kTileH / 4) + b; }, easu_strict_queue_capacity(kTileW * kTileH), tid, [&](int id) {
+      easu_strict_rounds<kThreads, kTileH / 4>(sq, redo_all, [&](int b) { return tid * (kTileH / 4) + b; }, easu_strict_queue_capacity(kTileW * kTileH), tid, [&](int id) {
         const int sub = id & 3, k = (id >> 2) & (kTileH / 16 - 1), t = id / (kTileH / 4);
         const int qx = t & 31, qy = (kTileH / 8) * (t >> 6) + 2 * k + ((t >> 5) & 1);
         const int ox = ox0 + 2 * qx + (sub & 1), oy = oy0 + 2 * qy + (sub >> 1);
@@ -228,7 +227,7 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
     // group = (wave, column): the lane's four rows; pixel id = 4 * group + row.  The queued pixels densely over the workgroup's first
     // lanes, in the reference's operation order
     static_assert(S2 || kRowsPerWave == 4, "a group is a lane's four rows");
-    easu_strict_rounds<kThreads>(sq, redo, [&](int b) { return 4 * (wave * 64 + col) + b; }, easu_strict_queue_capacity(kTileW * kTileH), tid, [&](int id) {
+    easu_strict_rounds<kThreads, 4>(sq, redo, [&](int b) { return 4 * (wave * 64 + col) + b; }, easu_strict_queue_capacity(kTileW * kTileH), tid, [&](int id) {
       const int qx = ox0 + ((id >> 2) & 63), qy = oy0 + 4 * (id >> 8) + (id & 3);
       float px = (float)(qx + a.origin_x) * c0x + c0z, py = (float)(qy + a.origin_y) * c0y + c0w;  // :324-326, as above
       const float fx = floorf(px), fy = floorf(py);

@@ -28,7 +28,6 @@ __global__ void __launch_bounds__(kThreads) fused_kernel(const FusedArgs a) {
   texel_t* const mid = reinterpret_cast<texel_t*>(smem + easu_lds_region_bytes(cap));  // [kMidH][kMidW]
   static_assert(!STRICT || (!EXACT && !COLOR), "F-strict: the plain kernel's default arithmetic");
   const EasuStrictQueue sq = easu_strict_queue_carve(reinterpret_cast<char*>(mid) + ((sizeof(texel_t) * kMidW * kMidH + 15) & ~(size_t)15));  // (STRICT)
-  if constexpr (STRICT) easu_strict_queue_reset(sq, threadIdx.x);
 
   const int tiles_per_frame = a.tiles_x * a.tiles_y;
   const int t = xcd_swizzle(blockIdx.x, tiles_per_frame * a.frames);
@@ -113,7 +112,7 @@ __global__ void __launch_bounds__(kThreads) fused_kernel(const FusedArgs a) {
   }
   if constexpr (STRICT) {
     // pixel id = its index in the LDS tile.  Bit b < 7 of a lane's mask: row wave + 4 b of its column; bit 7: the last wave's leftover pixel
-    easu_strict_rounds<kThreads>(
+    easu_strict_rounds<kThreads, 8>(
         sq, redo, [&](int b) { return b == 7 ? (lane >> 1) * kMidW + kTileW + (lane & 1) : (wave + 4 * b) * kMidW + redo_col; },
         easu_strict_queue_capacity(kMidW * kMidH), tid, [&](int id) {
           const int my = id / kMidW, mx = id - my * kMidW;

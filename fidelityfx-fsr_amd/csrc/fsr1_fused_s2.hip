@@ -42,7 +42,7 @@ size_t fused_s2_strict_lds_bytes(int fmt, int waves) { return fused_s2_lds_bytes
 constexpr int kFs2MaxSteps = 8;
 // (override_fused_s2_steps, csrc/fsr1_overrides.h: 0 in the product library; libfsr1_hip_test.so can force a number of steps per run —
 //  any number gives the same image, tests/test_gpu_parity.py::test_fused_exact_2x_run_steps)
-int fused_s2_run_steps(int width, int height, int frames, int cus, int wgs_per_cu, bool overlapped) {
+int fused_s2_run_steps(int width, int height, int frames, int cus, int wgs_per_cu, bool overlapped, bool strict) {
   if (const int forced = override_fused_s2_steps(); forced > 0) return forced;
   const long long tiles1 = (long long)((width + kFs2OutW - 1) / kFs2OutW) * ((height + kFs2Step - 3) / (kFs2Step - 2)) * frames;
   // (cus: the device's compute units — 256 on MI355X, where the rule was measured; wgs_per_cu: what the kernel's LDS admits, 7 for
@@ -54,7 +54,9 @@ int fused_s2_run_steps(int width, int height, int frames, int cus, int wgs_per_c
   // one-step 58.2-58.6, tall tile 56.6, S = 2 / 3 / 4 / 6 / 8: 55.8 / 54.8-55.1 / 53.9-54.2 / 54.2-54.3 / 55.9; 1440p output:
   // 26.3-26.6 one-step, 25.2-25.3 / 25.3-25.4 / 25.7 / 28.5 at 2 / 3 / 4 / 6): about 1.25 residencies of runs.
   const long long s = overlapped ? (4 * tiles1 + 5 * slots / 2) / (5 * slots) : tiles1 / (5 * slots);
-  return (int)(s < 1 ? 1 : s > kFs2MaxSteps ? kFs2MaxSteps : s);
+  // (F-strict: every step ends with the serial re-evaluation of its queued pixels — at most two steps per run, fsr1_api.hip)
+  const long long most = strict ? 2 : kFs2MaxSteps;
+  return (int)(s < 1 ? 1 : s > most ? most : s);
 }
 
 // One-step launches of a frame that fills the chip take the TALL tile: a 512-thread workgroup (8 waves) whose single step is 32 EASU
@@ -83,7 +85,7 @@ void fused_s2_geometry(int width, int height, int steps, int* tiles_x, int* tile
 // ones that fail re-evaluated in the reference's operation order INTO THE RING before the RCAS phase reads it — the EASU half is
 // bit-identical to EXACT's, the RCAS half runs the default arithmetic (include/fsr1_hip.h, FSR1_FLAG_MATH_STRICT).
 template <int FMT, bool EXACT, bool RUN, int WAVES, bool STRICT = false>
-__global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(WAVES == 4 ? 7 : 6, 8))) fused_s2_kernel(const FusedArgs a) {
+__global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(WAVES == 4 && !(STRICT && !RUN) ? 7 : 6, 8))) fused_s2_kernel(const FusedArgs a) {
   typedef typename Pixel<FMT>::T texel_t;
   static_assert(WAVES == 4 || WAVES == 8, "a wave filters two quad rows = four EASU rows of a step");
   constexpr int kFs2FpH = 2 * WAVES + 3, kFs2Step = 4 * WAVES, kFs2Ring = kFs2Step + 2;  // footprint rows, EASU rows per step, ring rows (shadow the 4-wave constants)
@@ -129,7 +131,6 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
     int tid = threadIdx.x;
     if (RUN) asm volatile("" : "+v"(tid));  // per-lane addresses are re-derived in every step rather than kept in registers across the filter
     const int lane = tid & 63;
-    if constexpr (STRICT) easu_strict_queue_reset(sq, tid);  // (the staging's barriers order it before this step's pushes)
     easu_stage_footprint<FMT, false, EXACT, kFs2FpW, kFs2FpH, kThreads, 0, STRICT>(l, a.in, in_frame, 31 * tx - 2, ((ay0 + 1) >> 1) - 2 + (a.origin_y >> 1),
                                                                                   kFs2FpW, kFs2FpH, tid);
     // (its two barriers also separate this step's ring writes from the previous step's RCAS reads)
@@ -167,7 +168,7 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
           m0[0] = m0[1] = m0[kFs2MidW] = m0[kFs2MidW + 1] = Pixel<FMT>::zero();  // outside the image: 0 (FSR_Pass.hlsl:45,61)
           redo = (xin0 && yin0 ? 1u : 0u) | (xin1 && yin0 ? 2u : 0u) | (xin0 && yin1 ? 4u : 0u) | (xin1 && yin1 ? 8u : 0u);
         }
-        easu_strict_rounds<kThreads>(sq, redo, [&](int b) { return 4 * tid + b; }, easu_strict_queue_capacity(kFs2MidW * kFs2Step), tid, [&](int id) {
+        easu_strict_rounds<kThreads, 4>(sq, redo, [&](int b) { return 4 * tid + b; }, easu_strict_queue_capacity(kFs2MidW * kFs2Step), tid, [&](int id) {
           const int sub = id & 3, t = id >> 2, rqx = t & 31, rqy = 2 * (t >> 6) + ((t >> 5) & 1);
           int rslot = base + 2 + 2 * rqy;
           rslot -= rslot >= kFs2Ring ? kFs2Ring : 0;

@@ -657,54 +657,81 @@ __device__ __forceinline__ typename Pixel<FMT>::T easu_strict_pixel(const EasuLd
   return easu_resolve<FMT, true>(m, p, false);
 }
 
-// The workgroup's queue of pixels to re-evaluate: 16-bit pixel ids (the kernel's own numbering of its tile) behind a counter.  A lane
-// pushes ONCE, after its pixel loop, whatever it has collected (the atomic's wave-level combination is then paid once per wave; a
-// push per loop pass, or a queue of lane groups expanded before the re-evaluation, were both measured slower: the second puts a serial
-// step and a barrier on the workgroup's critical path — profiles/ab_r06).  The queue holds an EIGHTH of the tile's pixels (natural
-// content queues 2-4 %): LDS per workgroup decides how many workgroups a CU holds, and a queue for every pixel of a 64 x 32 tile
-// (4 KB) costs the generic kernel one of its four (1440p -> 4K: +7 % for the queue alone, profiles/ab_r06/r6c1_strict_breakdown.log).
-// What does not fit stays with its lane and is pushed again in the next round (easu_strict_rounds) — content that queues every pixel
-// runs tile_pixels / capacity rounds of fully occupied re-evaluation passes.
+// The workgroup's queue of pixels to re-evaluate: 16-bit pixel ids (the kernel's own numbering of its tile), one SEGMENT per wave.  A
+// wave fills its own segment with ballots and lane counts (v_mbcnt) — no atomic, no LDS round trip, nothing serial — once, after its pixel
+// loop; the re-evaluation then walks the segments as one dense list.  (Measured on the way, profiles/ab_r06: a shared queue behind an LDS
+// atomic costs the 64 x 16 exact-2x kernel 2.8 us of 43.5 — the compiler combines the lanes' increments in a scalar loop over the pushing
+// lanes, at the very end of each wave's life; a queue of lane groups expanded before the re-evaluation puts a serial step and a barrier on
+// the workgroup's critical path and is slower still.)  The queue holds an EIGHTH of the tile's pixels, at least 256 (natural content
+// queues 2-4 %): LDS per workgroup decides how many workgroups a CU holds, and a queue for every pixel of a 64 x 32 tile (4 KB) costs the
+// generic kernel one of its four (1440p -> 4K: +7 % for the queue alone, r6c1_strict_breakdown.log).  What finds no room stays with its
+// lane and is pushed again in the next round (easu_strict_rounds): content that queues every pixel runs tile_pixels / capacity rounds of
+// fully occupied re-evaluation passes.
 struct EasuStrictQueue {
-  uint32_t* count;      // pushes of this round, may exceed the capacity
-  unsigned short* ids;  // [capacity]
+  uint32_t* count;      // [waves] pushes of each wave in this round, may exceed the segment
+  unsigned short* ids;  // [waves][capacity / waves]
 };
-// (at least 256: four waves' worth per round where the tile is 1024 pixels)
 __host__ __device__ constexpr int easu_strict_queue_capacity(int tile_pixels) { return tile_pixels / 8 < 256 ? 256 : tile_pixels / 8; }
 // bytes of LDS behind the footprint region for a tile of `tile_pixels` pixels
-__host__ __device__ constexpr size_t easu_strict_queue_bytes(size_t tile_pixels) { return 16 + (((size_t)easu_strict_queue_capacity((int)tile_pixels) * 2 + 15) & ~(size_t)15); }
+__host__ __device__ constexpr size_t easu_strict_queue_bytes(size_t tile_pixels) { return 32 + (((size_t)easu_strict_queue_capacity((int)tile_pixels) * 2 + 15) & ~(size_t)15); }
 __device__ __forceinline__ EasuStrictQueue easu_strict_queue_carve(char* p) {
-  return EasuStrictQueue{reinterpret_cast<uint32_t*>(p), reinterpret_cast<unsigned short*>(p + 16)};
+  return EasuStrictQueue{reinterpret_cast<uint32_t*>(p), reinterpret_cast<unsigned short*>(p + 32)};
 }
-__device__ __forceinline__ void easu_strict_queue_reset(const EasuStrictQueue& q, int tid) {
-  if (tid == 0) *q.count = 0;
-}
-// Appends the pixels whose bits are set in `mask` (bit b = pixel id_of(b)), for this lane; returns the bits that found no room.
-template <class IdOf>
-__device__ __forceinline__ uint32_t easu_strict_push(const EasuStrictQueue& q, uint32_t mask, const IdOf& id_of, int capacity) {
-  if (mask) {
-    uint32_t at = atomicAdd(q.count, (uint32_t)__builtin_popcount(mask));
-    while (mask && at < (uint32_t)capacity) {
-      q.ids[at++] = (unsigned short)id_of(__builtin_ctz(mask));
-      mask &= mask - 1;
+// One wave appends the pixels whose bits are set in its lanes' `mask` (bit b < NBITS = pixel id_of(b)) to its segment; returns, per lane,
+// the bits that found no room.  Every lane of the wave takes part.
+template <int NBITS, class IdOf>
+__device__ __forceinline__ uint32_t easu_strict_push(const EasuStrictQueue& q, uint32_t mask, const IdOf& id_of, int wave, int segment) {
+  unsigned short* const seg = q.ids + wave * segment;
+  uint32_t used = 0;  // wave-uniform
+#pragma unroll
+  for (int b = 0; b < NBITS; ++b) {
+    const bool mine = (mask >> b) & 1u;
+    const unsigned long long vote = __ballot(mine);
+    if (vote) {
+      const uint32_t at = used + __builtin_amdgcn_mbcnt_hi((uint32_t)(vote >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)vote, 0u));
+      if (mine && at < (uint32_t)segment) {
+        seg[at] = (unsigned short)id_of(b);
+        mask &= ~(1u << b);
+      }
+      used += (uint32_t)__builtin_popcountll(vote);
     }
   }
+  if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0) q.count[wave] = used;
   return mask;
 }
 // The re-evaluation rounds.  Every thread of the workgroup calls this once after its pixel loop with the pixels it collected
-// (`mask`, bit b = pixel id_of(b)); `redo(id)` re-evaluates and stores pixel `id`.  PRE: the queue was reset before a barrier.
-// The first barrier inside also orders the caller's pixel loop before the re-evaluation; none follows the last round.
-template <int THREADS, class IdOf, class Redo>
+// (`mask`, bit b < NBITS = pixel id_of(b)); `redo(id)` re-evaluates and stores pixel `id`.  The first barrier inside also orders the
+// caller's pixel loop before the re-evaluation; none follows the last round.
+template <int THREADS, int NBITS, class IdOf, class Redo>
 __device__ __forceinline__ void easu_strict_rounds(const EasuStrictQueue& q, uint32_t mask, const IdOf& id_of, int capacity, int tid, const Redo& redo) {
+  constexpr int kWaves = THREADS / 64;
+  const int segment = capacity / kWaves;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   for (;;) {
-    mask = easu_strict_push(q, mask, id_of, capacity);
+    mask = easu_strict_push<NBITS>(q, mask, id_of, wave, segment);
     __syncthreads();
-    const int pushed = (int)*q.count, n = pushed < capacity ? pushed : capacity;
-    for (int i = tid; i < n; i += THREADS) redo((int)q.ids[i]);
-    if (pushed <= capacity) break;  // (workgroup-uniform)
-    __syncthreads();                // everyone has read the count and its ids
-    easu_strict_queue_reset(q, tid);
-    __syncthreads();
+    int held[kWaves], n = 0;
+    bool more = false;  // (workgroup-uniform)
+#pragma unroll
+    for (int w = 0; w < kWaves; ++w) {
+      const int c = __builtin_amdgcn_readfirstlane((int)q.count[w]);  // (uniform: keep the table in scalar registers)
+      more |= c > segment;
+      held[w] = c < segment ? c : segment;
+      n += held[w];
+    }
+    for (int i = tid; i < n; i += THREADS) {
+      int j = i, at = 0;
+#pragma unroll
+      for (int w = 0; w < kWaves - 1; ++w) {
+        const bool beyond = j >= held[w];
+        j -= beyond ? held[w] : 0;
+        at += beyond ? segment : 0;
+        if (!beyond) break;
+      }
+      redo((int)q.ids[at + j]);
+    }
+    if (!more) break;
+    __syncthreads();  // everyone has read the counts and its ids
   }
 }
 

@@ -14,7 +14,7 @@
  * data ever crosses a link.  Rank 0 prints one JSON line.
  *
  *   fsr1_runner [--gpus N] [--frames F] [--in WxH] [--out WxH] [--steps K] [--warmup W]
- *               [--pipeline two-pass|fused|easu|auto] [--math f|exact|h] [--sharpness STOPS] [--hdr]
+ *               [--pipeline two-pass|fused|easu|auto] [--math f|strict|exact|h] [--sharpness STOPS] [--hdr]
  *               [--stages BITS] [--grain AMOUNT] [--ring R] [--bands] [--streams S] [--dry-run [--dry-fail RANK]]
  *
  * --bands: strong scaling of ONE frame stream instead of weak scaling over frames — every GPU holds the whole
@@ -395,7 +395,7 @@ static int parse_size(const char* s, int* w, int* h) { return sscanf(s, "%dx%d",
 
 static void usage(void) {
   puts("usage: fsr1_runner [--gpus N] [--frames F] [--in WxH] [--out WxH] [--steps K] [--warmup W]\n"
-       "                   [--pipeline two-pass|fused|easu|auto] [--math f|exact|h] [--sharpness STOPS] [--hdr]\n"
+       "                   [--pipeline two-pass|fused|easu|auto] [--math f|strict|exact|h] [--sharpness STOPS] [--hdr]\n"
        "                   [--stages BITS] [--grain AMOUNT]   (colour stages: 1 SRTM, 2 grain, 4 SRTM inverse, 8/16 TEPD 8/10-bit)\n"
        "                   [--ring R]   (input / output sets to rotate over; default: more than 1 GiB, 4 x the Infinity Cache)\n"
        "                   [--bands]    (one frame stream split into row bands over the GPUs instead of frames per GPU)\n"
@@ -433,6 +433,7 @@ int main(int argc, char** argv) {
       ++i;
     } else if (!strcmp(a, "--math")) {
       if (!strcmp(v, "f")) o.math = 0; else if (!strcmp(v, "exact")) o.math = FSR1_FLAG_MATH_EXACT;
+      else if (!strcmp(v, "strict")) o.math = FSR1_FLAG_MATH_STRICT;  /* EASU bit-identical to FsrEasuF, final image within 1 ULP of the chain */
       else if (!strcmp(v, "h")) o.math = FSR1_FLAG_MATH_PACKED_FP16;
       else { fprintf(stderr, "bad --math %s\n", v); return 2; }
       ++i;
@@ -495,7 +496,7 @@ int main(int argc, char** argv) {
            (double)pixels / sec / 1e6, o.gpus, (unsigned long long)frames, o.steps, o.warmup, sec * 1e3 / o.steps, sec, o.bands ? "strong" : "weak",
            o.in_w, o.in_h, o.out_w, o.out_h,
            o.pipeline == 0 ? "two-pass" : (o.pipeline == 1 ? "fused" : (o.pipeline == 2 ? "easu" : "auto")),
-           ran == 0 ? "two-pass" : (ran == 1 ? "fused" : "easu"), o.math == FSR1_FLAG_MATH_EXACT ? "exact" : (o.math ? "h" : "f"), o.stages, bytes / sec / 1e9,
+           ran == 0 ? "two-pass" : (ran == 1 ? "fused" : "easu"), o.math == FSR1_FLAG_MATH_EXACT ? "exact" : (o.math == FSR1_FLAG_MATH_STRICT ? "strict" : (o.math ? "h" : "f")), o.stages, bytes / sec / 1e9,
            bytes / sec / 1e9 / (8000.0 * o.gpus), o.dry ? 0 : o.gpus, o.dry ? o.gpus : ws[0].comm_ranks, ws[0].ring, ran == 0 ? (o.streams > 1 ? "one per stream" : "reused") : "none", o.bands, o.streams,
            o.dry ? "true" : "false");
     for (int i = 0; i < o.gpus; ++i) printf("%s%.3f", i ? ", " : "", (double)gathered[3 * i + 2] * 1e-6);

@@ -16,7 +16,7 @@ from conftest import ROOT
 def geometry(tmp_path_factory):
     text = open(os.path.join(ROOT, "fidelityfx-fsr_amd", "csrc", "fsr1_fused_s2.hip")).read()
     consts = re.search(r"constexpr int kFs2OutW = .*?;\nconstexpr int kFs2QH = .*?;", open(os.path.join(ROOT, "fidelityfx-fsr_amd", "csrc", "fsr1_device.h")).read(), flags=re.S)
-    steps = re.search(r"constexpr int kFs2MaxSteps = .*?\nint fused_s2_run_steps\(int width, int height, int frames, int cus, int wgs_per_cu, bool overlapped\) \{.*?\n\}\n", text, flags=re.S)
+    steps = re.search(r"constexpr int kFs2MaxSteps = .*?\nint fused_s2_run_steps\(int width, int height, int frames, int cus, int wgs_per_cu, bool overlapped, bool strict\) \{.*?\n\}\n", text, flags=re.S)
     geo = re.search(r"bool fused_s2_tall_tiles\(int width, int height, int frames, int steps, int cus, int fmt\) \{.*?\n\}\n\nvoid fused_s2_geometry\(int width, int height, int steps, int\* tiles_x, int\* tiles_y, int step_rows\) \{.*?\n\}\n", text, flags=re.S)
     assert consts and steps and geo, "host geometry functions not found in fsr1_fused_s2.hip"
     tmp = tmp_path_factory.mktemp("walk")
@@ -25,15 +25,15 @@ def geometry(tmp_path_factory):
     src.write_text("#include <cstdio>\n#include <cstdlib>\n#include \"fsr1_hip_test.h\"\n#include \"fsr1_overrides.h\"\nusing namespace fsr1;\n" + consts.group(0) + "\n" + steps.group(0) + geo.group(0) +
                    "int main(int argc, char** argv) { int w = atoi(argv[1]), h = atoi(argv[2]), f = atoi(argv[3]), cus = atoi(argv[4]);\n"
                    "  fsr1_debug_fused_run_steps(atoi(argv[5]));  // the test hook (include/fsr1_hip_test.h); 0 = the rule\n"
-                   "  int s = fused_s2_run_steps(w, h, f, cus, argc > 6 ? atoi(argv[6]) : 7, argc > 7 && atoi(argv[7])), tx, ty; fused_s2_geometry(w, h, s, &tx, &ty, kFs2Step);\n"
+                   "  int s = fused_s2_run_steps(w, h, f, cus, argc > 6 ? atoi(argv[6]) : 7, argc > 7 && atoi(argv[7]), argc > 8 && atoi(argv[8])), tx, ty; fused_s2_geometry(w, h, s, &tx, &ty, kFs2Step);\n"
                    "  int tall = fused_s2_tall_tiles(w, h, f, s, cus, 0), ttx = 0, tty = 0; if (tall) fused_s2_geometry(w, h, s, &ttx, &tty, 2 * kFs2Step);\n"
                    "  std::printf(\"%d %d %d %d %d %d %d\\n\", s, tx, ty, kFs2Step, tall, ttx, tty); return 0; }\n")
     exe = tmp / "walk"
     csrc = os.path.join(ROOT, "fidelityfx-fsr_amd", "csrc")
     subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", csrc, "-I", os.path.join(ROOT, "include"), "-o", str(exe), str(src), os.path.join(csrc, "fsr1_test_hooks.cpp")])
 
-    def run(w, h, frames, forced=0, cus=256, wgs=7, overlapped=0):
-        return [int(x) for x in subprocess.check_output([str(exe), str(w), str(h), str(frames), str(cus), str(forced), str(wgs), str(overlapped)], text=True).split()]
+    def run(w, h, frames, forced=0, cus=256, wgs=7, overlapped=0, strict=0):
+        return [int(x) for x in subprocess.check_output([str(exe), str(w), str(h), str(frames), str(cus), str(forced), str(wgs), str(overlapped), str(strict)], text=True).split()]
     return run
 
 
@@ -67,6 +67,13 @@ def test_overlapped_launches_walk_longer_runs(geometry):
         s, tx, ty = geometry(w, h, 1, overlapped=1)[:3]
         run = 16 * s - 2
         assert tx * 62 >= w and (ty - 1) * run < h <= ty * run
+
+
+def test_strict_launches_walk_at_most_two_steps(geometry):
+    """F-strict (round 6): every step ends with the serial re-evaluation of its queued pixels while the other waves wait — runs of at most
+    two steps, alone or overlapped (profiles/ab_r06/r6c5_strict_fused_shapes.log); a forced number of steps is still taken."""
+    assert geometry(3840, 2160, 1, strict=1)[0] == 1 and geometry(3840, 2160, 1, overlapped=1, strict=1)[0] == 2
+    assert geometry(7680, 4320, 16, strict=1)[0] == 2 and geometry(3840, 2160, 1, forced=5, strict=1)[0] == 5
 
 
 def test_tall_tiles_for_one_step_launches_that_fill_the_chip(geometry):

@@ -50,12 +50,15 @@ def test_no_kernel_spills_or_uses_scratch(meta):
     ("fsr1::easu_kernel<0, false, false, 0, false, false, 48, 32, 8, true>", 64),
     ("fsr1::easu_kernel<0, false, false, 0, false, false, 56, 32, 8, true>", 64),
     # fused exact-2x launch, one-step and walking form: seven workgroups per CU is what their LDS admits
-    ("fsr1::fused_s2_kernel<0, false, false, 4>", 72),
-    ("fsr1::fused_s2_kernel<0, false, true, 4>", 72),
-    ("fsr1::fused_s2_kernel<0, true, true, 4>", 72),
+    ("fsr1::fused_s2_kernel<0, false, false, 4, false>", 72),
+    ("fsr1::fused_s2_kernel<0, false, true, 4, false>", 72),
+    ("fsr1::fused_s2_kernel<0, true, true, 4, false>", 72),
     # the tall one-step tile (512 threads): three workgroups of eight waves per CU = six waves per SIMD
-    ("fsr1::fused_s2_kernel<0, false, false, 8>", 80),
-    ("fsr1::fused_s2_kernel<0, true, false, 8>", 80),
+    ("fsr1::fused_s2_kernel<0, false, false, 8, false>", 80),
+    ("fsr1::fused_s2_kernel<0, true, false, 8, false>", 80),
+    # ... and their F-strict forms: the walking one at seven waves, the one-step tile at six
+    ("fsr1::fused_s2_kernel<0, false, true, 4, true>", 72),
+    ("fsr1::fused_s2_kernel<0, false, false, 4, true>", 80),
     # packed fp16
     ("fsr1::easu_h_kernel<true>", 64),
     ("fsr1::rcas_h_kernel<false>", 64),
@@ -69,7 +72,7 @@ def test_walking_fused_kernel_fits_seven_workgroups_of_sgprs(meta):
     """256-thread workgroups are admitted per CU up to floor(800 / (ceil(sgpr / 16) * 16 + 16)) (MI355X_MICROARCH.md, residency):
     seven workgroups need at most 96 SGPRs."""
     for k, v in meta.items():
-        if k.startswith("fsr1::fused_s2_kernel<") and k.endswith(", 4>"):
+        if k.startswith("fsr1::fused_s2_kernel<") and (k.endswith(", 4, false>") or k.endswith(", true, 4, true>")):
             assert 800 // ((v["sgpr"] + 15) // 16 * 16 + 16) >= 7, (k, v)
 
 
