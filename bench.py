@@ -114,8 +114,8 @@ class Telemetry:
         self._open = {}
         self._stop = threading.Event()
         self._thread = None
+        node = None
         try:
-            node = None
             try:
                 p = torch.cuda.get_device_properties(dev_index)
                 bdf = "%04x:%02x:%02x.0" % (p.pci_domain_id, p.pci_bus_id, p.pci_device_id)
@@ -141,6 +141,22 @@ class Telemetry:
                         f = os.path.join(hw, name)
                         if self.power is None and os.path.exists(f) and self._read(f) is not None:
                             self.power = f
+        except Exception:
+            pass
+        # static facts of the device the figures are read against: the package power cap, the compute-partition mode (the kernels' XCD
+        # swizzle assumes SPX: 8 XCDs behind one device) and the NUMA node / local CPUs of its PCIe root
+        self.node = node
+        self.power_cap_w = self.partition = self.numa_node = self.local_cpus = None
+        try:
+            if self.power:
+                v = self._read(os.path.join(os.path.dirname(self.power), "power1_cap"))
+                self.power_cap_w = round(v / 1e6, 1) if v else None
+            if self.node:
+                for attr, name in (("partition", "current_compute_partition"), ("numa_node", "numa_node"), ("local_cpus", "local_cpulist")):
+                    try:
+                        setattr(self, attr, open(os.path.join(self.node, name)).read().strip())
+                    except OSError:
+                        pass
         except Exception:
             pass
         if self.freq or self.power:
@@ -175,6 +191,38 @@ class Telemetry:
         if self._thread is not None:
             self._thread.join(timeout=1.0)
 
+    def violations(self, dev_index):
+        """The SMU's throttle ("violation") accumulators of this GPU from `amd-smi metric --violation --json` (best effort, ~1 s of host time,
+        called outside every timed region): a dict of the numeric fields, or None.  The DIFFERENCE of two calls around a load window says
+        which limiter was active during it (ppt = the package power cap, thermal, ...)."""
+        import shutil
+        import subprocess
+        exe = shutil.which("amd-smi") or ("/opt/rocm/bin/amd-smi" if os.path.exists("/opt/rocm/bin/amd-smi") else None)
+        if not exe:
+            return None
+        try:
+            out = subprocess.run([exe, "metric", "-g", str(dev_index), "--violation", "--json"], capture_output=True, text=True, timeout=20).stdout
+            doc = json.loads(out[out.index("{") if "{" in out and (out.lstrip()[:1] != "[") else out.index("["):])
+            flat = {}
+
+            def walk(prefix, v):
+                if isinstance(v, dict):
+                    if set(v) >= {"value"} and isinstance(v.get("value"), (int, float)):
+                        flat[prefix] = v["value"]
+                    else:
+                        for k, x in v.items():
+                            walk((prefix + "." if prefix else "") + str(k), x)
+                elif isinstance(v, list):
+                    for i, x in enumerate(v):
+                        walk(prefix if len(v) == 1 else "%s[%d]" % (prefix, i), x)
+                elif isinstance(v, (int, float)) and not isinstance(v, bool):
+                    flat[prefix] = v
+            walk("", doc)
+            flat = {k.split("violation_status.")[-1]: v for k, v in flat.items() if "gpu" != k}
+            return flat or None
+        except Exception:
+            return None
+
     def summary(self, label):
         """(median MHz, mean W, samples) over the spans recorded under `label`; None where nothing was read."""
         spans = self.spans.get(label, [])
@@ -198,6 +246,102 @@ def gather_pairs(a, b, device):
         rows = [t.tolist() for t in out]
     clean = lambda v: None if v != v else v  # noqa: E731
     return [clean(r[0]) for r in rows], [clean(r[1]) for r in rows]
+
+
+def gather_row(values, device):
+    """Every rank's row of floats (None = "not read") in rank order: one counters-only collective."""
+    import torch
+    import torch.distributed as dist
+    nan = float("nan")
+    mine = torch.tensor([nan if v is None else float(v) for v in values], dtype=torch.float64, device=device)
+    if not (dist.is_available() and dist.is_initialized()):
+        rows = [mine.tolist()]
+    else:
+        out = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+        dist.all_gather(out, mine)
+        rows = [t.tolist() for t in out]
+    return [[None if v != v else v for v in r] for r in rows]
+
+
+TELEMETRY_WINDOW_S = 1.2
+TELEMETRY_MIN_SAMPLES = 200  # a clock / power figure from fewer samples of the load is marked unreliable (round 5's K = 20 line: 57 samples, 20 % low)
+
+
+def telemetry_block(rows, source, period_ms, window_s, partition, extra=None):
+    """The line's `telemetry` object from every rank's (mhz, watts, samples, cap_w, ppt_delta, thermal_delta) row."""
+    samples = [int(r[2]) if r[2] is not None else 0 for r in rows]
+    caps = [r[3] for r in rows]
+    t = {"source": source, "period_ms": period_ms,
+         "window": "a dedicated window of %.1f s of the headline's pipelined load per rank, after the clock ramp and before the warm-up and the timed regions "
+                   "(outside all of them): long enough for >= %d samples whatever --steps is" % (window_s, TELEMETRY_MIN_SAMPLES),
+         "samples_per_rank": samples, "samples_rank0": samples[0] if samples else 0,
+         "reliable": bool(samples) and min(samples) >= TELEMETRY_MIN_SAMPLES,
+         "power_cap_w": caps,
+         "at_power_cap": [None if (r[1] is None or r[3] is None) else bool(r[1] >= 0.95 * r[3]) for r in rows],
+         "throttle_accumulator_delta": {"ppt": [r[4] for r in rows], "thermal": [r[5] for r in rows],
+                                        "note": "SMU violation accumulators (amd-smi metric --violation) after minus before the window, per rank: which limiter was "
+                                                "active under the load; null where amd-smi does not report them"},
+         "compute_partition": partition}
+    if not t["reliable"]:
+        t["unreliable"] = "fewer than %d samples of the load on at least one rank: per_rank_mhz / per_rank_watts under-read a short load" % TELEMETRY_MIN_SAMPLES
+    if extra:
+        t.update(extra)
+    return t
+
+
+def parse_cpulist(text):
+    """"0-63,128-191" -> the set of CPU numbers (sysfs local_cpulist syntax)"""
+    cpus = set()
+    for part in (text or "").strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus.update(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def bind_to_gpu_cpus(tele, enabled=True):
+    """Pins this rank's process to the CPUs local to its GPU's PCIe root (sysfs local_cpulist / numa_node of the device: VERDICT r5, weak 8
+    — every rank submits ~16 k steps/s through ctypes, and on a two-socket host half the ranks would otherwise launch across the socket
+    link).  Best effort; returns what the line prints as config.cpu_binding."""
+    info = {"numa_node": tele.numa_node, "local_cpus": tele.local_cpus, "applied": False}
+    try:
+        cpus = parse_cpulist(tele.local_cpus) & os.sched_getaffinity(0)
+        if enabled and cpus:
+            os.sched_setaffinity(0, cpus)
+            info["applied"] = True
+            info["cpus_in_mask"] = len(cpus)
+    except (OSError, ValueError, AttributeError) as e:
+        info["error"] = str(e)[:80]
+    return info
+
+
+def submission_ceiling(fsr, torch, device, streams, seconds=0.25):
+    """Steps per second ONE rank's host thread can push through fsr1_pipeline_upscale (ctypes, the bench's own path): 16 x 16 -> 32 x 32
+    frames, whose kernels take no time to speak of, submitted for `seconds` (synchronising every 256 so the queues stay bounded), two
+    dispatches per step like the headline.  Compared with what the headline needs (1 / ms_per_step): the host must not be what a rank —
+    or eight of them on one host — waits for (Next 4)."""
+    src = torch.zeros(1, 16, 16, 4, dtype=torch.float16, device=device)
+    dsts = [torch.zeros(1, 32, 32, 4, dtype=torch.float16, device=device) for _ in range(max(2, streams))]
+    pipe = fsr.Pipeline(max(1, streams), managed=False)
+    pipe.reserve(32 * 32 * 8)
+    for i in range(64):
+        pipe.upscale(src, dsts[i % len(dsts)], sharpness=0.25, use_rcas=True, fused=0)
+    pipe.synchronize()
+    n, t0 = 0, time.perf_counter()
+    busy = 0.0
+    while True:
+        t1 = time.perf_counter()
+        for i in range(256):
+            pipe.upscale(src, dsts[i % len(dsts)], sharpness=0.25, use_rcas=True, fused=0)
+        busy += time.perf_counter() - t1
+        pipe.synchronize()
+        n += 256
+        if time.perf_counter() - t0 >= seconds:
+            break
+    pipe.close()
+    return {"steps_per_s": round(n / busy, 0), "us_per_step": round(busy / n * 1e6, 2), "steps": n,
+            "what": "host time of fsr1_pipeline_upscale (two dispatches, %d streams) per step through ctypes, 16x16 -> 32x32 frames" % max(1, streams)}
 
 
 def reduce_regions(region_seconds, device):
@@ -430,6 +574,12 @@ def main():
     ap.add_argument("--also", action="store_true",
                     help="with --gpus N > 1: run the also_measured pipelines as well (default at N > 1: headline regions only, so that no "
                          "collective runs outside them and one slow rank cannot distort five more sections)")
+    ap.add_argument("--no-pin", action="store_true", help="do not pin the rank's process to the CPUs local to its GPU's PCIe root (sysfs local_cpulist)")
+    ap.add_argument("--submit-only", action="store_true",
+                    help="measure only the host's submission ceiling (steps/s through fsr1_pipeline_upscale on 16x16 frames) on every rank and print it; "
+                         "with --gpus 8 --backend gloo --oversubscribe: eight processes contending on one host")
+    ap.add_argument("--no-telemetry-window", action="store_true",
+                    help="skip the dedicated 1.2 s load window the per-rank clock / power figures are sampled in (the line then marks them unreliable)")
     ap.add_argument("--no-latency", action="store_true", help="skip the single-frame latency block (N = 1 only)")
     ap.add_argument("--no-steady", action="store_true", help="skip the steady-state windows (K steps timed INSIDE a longer stream, fill / drain excluded)")
     ap.add_argument("--no-parity", action="store_true", help="skip the image-level parity block (N = 1 only; part of the cpu_baseline leg)")
@@ -493,6 +643,26 @@ def main():
         else:
             dist.init_process_group("gloo")
     coll_device = device if args.backend == "nccl" else torch.device("cpu")
+
+    tele = Telemetry(torch, dev_index)  # (the sampling thread runs from here on; figures are taken from labelled spans only)
+    cpu_binding = bind_to_gpu_cpus(tele, enabled=not args.no_pin)
+    if args.submit_only:
+        # the host's submission ceiling alone: every rank at the same time (a barrier in front), so that N ranks on one host contend as they
+        # would in a run; one JSON line with every rank's rate
+        if grouped:
+            dist.barrier()
+        mine = submission_ceiling(fsr, torch, device, args.streams, seconds=1.0)
+        rows = gather_row([mine["steps_per_s"], mine["us_per_step"]], coll_device)
+        tele.close()
+        if rank == 0:
+            need = 1e3 / 0.0610  # steps/s a rank submits at the headline's ~61 us per step
+            print(json.dumps({"metric": "host submission ceiling (steps/s per rank through fsr1_pipeline_upscale)", "value": min(r[0] for r in rows), "unit": "steps/s",
+                              "n_gpus": world, "per_rank_steps_per_s": [r[0] for r in rows], "per_rank_us_per_step": [r[1] for r in rows],
+                              "needed_steps_per_s": round(need, 0), "margin": round(min(r[0] for r in rows) / need, 2), "what": mine["what"],
+                              "streams": args.streams, "oversubscribed": bool(world > n_dev), "cpu_binding_rank0": cpu_binding, "data": "synthetic", "higher_is_better": True}), flush=True)
+        if grouped:
+            dist.destroy_process_group()
+        return
 
     in_w, in_h, out_w, out_h, frames = WORKLOADS[args.workload]
     math_flags = {"f": 0, "strict": fsr.FLAG_MATH_STRICT, "exact": fsr.FLAG_MATH_EXACT, "h": fsr.FLAG_MATH_PACKED_FP16}[args.math]
@@ -601,23 +771,41 @@ def main():
             torch.cuda.synchronize()
         return t
 
-    tele = Telemetry(torch, dev_index)
     # Device clock ramp (not part of W): an idle MI355X sits at ~100 MHz and needs a few milliseconds of load
     # to reach its working clocks; EASU then runs AT the 1400 W package power cap (sclk ~2.1 of 2.4 GHz), so the
     # steady state is what a frame stream sees.  ~0.2 s of the same steps, untimed.
+    viol0 = tele.violations(dev_index) if not args.no_telemetry_window else None  # (before the ramp: the GPU is idle anyway)
     t_ramp = time.perf_counter()
     i = 0
-    ramp_half = False
     while time.perf_counter() - t_ramp < 0.2:
         step(i)
         i += 1
         if i % 64 == 0:
             torch.cuda.synchronize()
-        if not ramp_half and time.perf_counter() - t_ramp >= 0.1:
-            # telemetry of the headline: the second half of the ramp (clocks and power have settled), the warm-up, the timed regions and
-            # the steady-state run — the same pipelined load throughout (a K = 20 region alone is 1.3 ms: less than one 2 ms sample)
-            ramp_half = True
-            tele.begin("headline")
+    torch.cuda.synchronize()
+    # Telemetry window (not part of W, outside every timed region): TELEMETRY_WINDOW_S of the headline's own pipelined load, sampled every 2 ms —
+    # 500+ samples whatever --steps is (round 5 sampled across the run itself: at the driver's K = 20 that was 57 samples of a 0.1 s load and
+    # read 20 % low).  The SMU's throttle accumulators are read before and after it: their difference says which limiter was active.
+    if not args.no_telemetry_window:
+        tele.begin("headline")
+        t_win = time.perf_counter()
+        while time.perf_counter() - t_win < TELEMETRY_WINDOW_S:
+            step(i)
+            i += 1
+            if i % 64 == 0:
+                torch.cuda.synchronize()
+        torch.cuda.synchronize()
+        tele.end("headline")
+    viol1 = tele.violations(dev_index) if viol0 is not None else None
+    if viol0 is not None:
+        # reading the accumulators took ~1 s of host time with the GPU idle (it drops to ~100 MHz within a millisecond): ramp again, so that
+        # the warm-up and the timed regions start from working clocks exactly as they did before the window existed
+        t_ramp = time.perf_counter()
+        while time.perf_counter() - t_ramp < 0.2:
+            step(i)
+            i += 1
+            if i % 64 == 0:
+                torch.cuda.synchronize()
     for i in range(args.warmup):
         step(i)
     fence()
@@ -687,7 +875,6 @@ def main():
     steady_regions = None
     if not args.no_steady and args.graph == 0:
         steady_regions = steady(step, args.steps, last_pipe_stream if pipe is not None else (lambda: None))
-    tele.end("headline")
 
     # the same K steps on ONE in-order stream (the method of rounds 1-3): the per-kernel stopwatch below is taken that way, and the
     # line's self-consistency check compares the kernels with THIS step (overlapped steps are shorter than the kernels they contain)
@@ -894,10 +1081,27 @@ def main():
         tele.end("latency")
         filt.OnDestroy()
 
+    # the host's submission ceiling (outside every timed region): steps/s this rank's thread can push through the pipeline — every rank at
+    # the same time, so that N ranks on one host contend as they do in the timed regions — against what the headline needs
+    if grouped:
+        dist.barrier()
+    submit = submission_ceiling(fsr, torch, device, args.streams)
+    submit_rows = gather_row([submit["steps_per_s"]], coll_device)
+
     # per-rank shader clock and package power during the headline regions (sysfs, best effort) — one counters-only collective
     tele.close()
     head_mhz, head_w, head_n = tele.summary("headline")
-    per_rank_mhz, per_rank_watts = gather_pairs(head_mhz, head_w, coll_device)
+
+    def viol_delta(*names):
+        """after - before of the first violation accumulator whose name contains one of `names` (None when not reported)"""
+        if not viol0 or not viol1:
+            return None
+        for k in viol1:
+            if any(n in k.lower() for n in names) and "acc" in k.lower() and k in viol0:
+                return viol1[k] - viol0[k]
+        return None
+    tele_rows = gather_row([head_mhz, head_w, head_n, tele.power_cap_w, viol_delta("ppt"), viol_delta("socket_thermal", "thermal")], coll_device)
+    per_rank_mhz, per_rank_watts = [r[0] for r in tele_rows], [r[1] for r in tele_rows]
 
     # algorithmic HBM bytes per launch (SURVEY.md §8d): EASU in+out, RCAS 2*out, fused in+out
     alg = {"easu": in_bytes + out_bytes, "rcas": 2 * out_bytes, "fused": in_bytes + out_bytes, "color": 2 * out_bytes}
@@ -956,6 +1160,7 @@ def main():
                        "binary_matches_sources": fsr._lib.build_id() == fsr._lib.source_hash(),
                        "intermediary": None if args.pipeline != "two-pass" else ("one per stream" if pipe is not None else ("rotated" if args.rotate_intermediary else "reused")),
                        "launch": launch_style(), "world_size_seen": dist.get_world_size() if grouped else 1,
+                       "cpu_binding": cpu_binding,
                        "collective_backend": (("rccl (torch.distributed 'nccl')" if args.backend == "nccl" else "gloo") if grouped else None),
                        "devices_visible": n_dev, "oversubscribed": bool(world > n_dev),
                        "streams": args.streams,
@@ -977,13 +1182,18 @@ def main():
             "streams": args.streams,
             "one_stream": {"value": round(total["pixels"] / median(one_regions) / 1e6, 1), "ms_per_step": round(median(one_regions) * 1e3 / args.steps, 5)},
             "per_rank_seconds": [round(t, 6) for t in per_rank_seconds],
-            # shader clock (median MHz) and package power (mean W) every rank's GPU showed under the headline's load (second half of the
-            # ramp, warm-up, timed regions, steady-state run), read from the amdgpu driver's sysfs files by a host thread; null where a
-            # box does not expose them
+            # shader clock (median MHz) and package power (mean W) every rank's GPU showed under the headline's load — a dedicated window of
+            # TELEMETRY_WINDOW_S of it before the timed regions (`telemetry.window`) — read from the amdgpu driver's sysfs files by a host
+            # thread; null where a box does not expose them
             "per_rank_mhz": per_rank_mhz, "per_rank_watts": per_rank_watts,
-            "telemetry": {"source": tele.source, "samples_rank0": head_n, "period_ms": tele.period * 1e3,
-                          "one_stream": dict(zip(("mhz", "watts", "samples"), tele.summary("one_stream"))),
-                          "latency": dict(zip(("mhz", "watts", "samples"), tele.summary("latency")))},
+            "telemetry": telemetry_block(tele_rows, tele.source, tele.period * 1e3, TELEMETRY_WINDOW_S, tele.partition,
+                                         extra={"one_stream": dict(zip(("mhz", "watts", "samples"), tele.summary("one_stream"))),
+                                                "latency": dict(zip(("mhz", "watts", "samples"), tele.summary("latency"))),
+                                                "violation_fields_rank0": sorted(viol1)[:24] if viol1 else None}),
+            "host_submission": dict(submit, per_rank_steps_per_s=[r[0] for r in submit_rows],
+                                    needed_steps_per_s=round(args.steps / total["seconds"], 0),
+                                    margin=round(min(r[0] for r in submit_rows) / (args.steps / total["seconds"]), 2),
+                                    note="margin = the slowest rank's ceiling / the steps per second the headline ran at: well above 1 means the host is not what a rank waits for"),
             "roofline": roof(dominant),
             "kernels": {k: roof(k) for k in kern},
             "pipeline_hbm": {"algorithmic_bytes_per_step": sum(alg[k] for k in kern),

@@ -260,6 +260,16 @@ static int device_cus() {
   return cus;
 }
 
+// log2 of the XCDs behind the current device, for the kernels' workgroup -> tile mapping (xcd_swizzle): an XCD of this family has 32 CUs
+// (MI355X: 256 CUs = 8 XCDs in SPX mode; the DPX / QPX / CPX partition modes expose devices of 128 / 64 / 32 CUs).  A CU count that is
+// not 32 x a power of two (another part) rounds down: any value only permutes the tiles.
+static int device_xcd_shift() {
+  const int xcds = device_cus() / 32;
+  int shift = 0;
+  while ((2 << shift) <= xcds && shift < 3) ++shift;
+  return shift;
+}
+
 // fsr1_params.fused = 2 ("auto"), on round-2 measurements: at exactly 2x the quad form of the fused
 // launch (fsr1_fused_s2.hip) beats the two dispatches at every size; elsewhere the fused launch pays off only where a frame
 // is launch-bound (<= 3 Mpixel of output per launch).  The fused kernels' tile (one-pixel apron) needs more LDS than EASU's:
@@ -331,6 +341,7 @@ static int easu_dispatch_impl(const fsr1_image* in, const fsr1_image* out, const
                               const fsr1_color_stages* stages, int origin_x, int origin_y, void* stream) {
   const Range range("easu", in, out);
   EasuArgs a;
+  a.xcd_shift = device_xcd_shift();
   int rc;
   if ((rc = check_flags(flags))) return rc;
   if ((rc = check_image(in, "easu input", &a.in))) return rc;
@@ -442,6 +453,7 @@ static int rcas_dispatch_impl(const fsr1_image* in, const fsr1_image* out, const
                               const fsr1_color_stages* stages, int rows_above, int rows_below, void* stream) {
   const Range range("rcas", in, out);
   RcasArgs a;
+  a.xcd_shift = device_xcd_shift();
   int rc;
   if ((rc = check_flags(flags))) return rc;
   // F-strict is EASU's property: RCAS runs the default arithmetic under it — except where EASU has no strict variant and runs EXACT
@@ -518,6 +530,7 @@ static int fused_dispatch_impl(const fsr1_image* in, const fsr1_image* out, cons
                                uint32_t flags, const fsr1_color_stages* stages, int origin_y, int rows_above, int rows_below, void* stream) {
   const Range range("easu_rcas_fused", in, out);
   FusedArgs a;
+  a.xcd_shift = device_xcd_shift();
   int rc;
   if ((rc = check_flags(flags))) return rc;
   if ((rc = check_image(in, "fused input", &a.in))) return rc;
@@ -584,6 +597,7 @@ int fsr1_color_dispatch(const fsr1_image* in, const fsr1_image* out, const fsr1_
                         void* stream) {
   const Range range("color", in, out);
   ColorPassArgs a;
+  a.xcd_shift = device_xcd_shift();
   int rc;
   if (flags & ~(uint32_t)(FSR1_FLAG_MATH_EXACT | FSR1_FLAG_MATH_PACKED_FP16))
     return fail(FSR1_ERR_INVALID_ARGUMENT, "color: flags may only hold FSR1_FLAG_MATH_EXACT or FSR1_FLAG_MATH_PACKED_FP16");

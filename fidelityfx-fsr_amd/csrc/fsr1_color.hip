@@ -20,7 +20,7 @@ __global__ void __launch_bounds__(kThreads) color_kernel(const ColorPassArgs a) 
   struct __attribute__((aligned(4))) in2_t { char bytes[2 * sizeof(in_t)]; };    // two adjacent texels, one access
   struct __attribute__((aligned(4))) out2_t { char bytes[2 * sizeof(out_t)]; };
   const int tiles_per_frame = a.tiles_x * a.tiles_y;
-  const int t = xcd_swizzle(blockIdx.x, tiles_per_frame * a.frames);
+  const int t = xcd_swizzle(blockIdx.x, tiles_per_frame * a.frames, a.xcd_shift);
   const int frame = t / tiles_per_frame;
   const int tf = t - frame * tiles_per_frame;
   const int ty = tf / a.tiles_x, tx = tf - ty * a.tiles_x;
@@ -104,7 +104,7 @@ __device__ __forceinline__ half2_t FsrTepdCHx2(half2_t c, half2_t dit, half_t k,
 
 __global__ void __launch_bounds__(kThreads) color_h_kernel(const ColorPassArgs a) {
   const int tiles_per_frame = a.tiles_x * a.tiles_y;
-  const int t = xcd_swizzle(blockIdx.x, tiles_per_frame * a.frames);
+  const int t = xcd_swizzle(blockIdx.x, tiles_per_frame * a.frames, a.xcd_shift);
   const int frame = t / tiles_per_frame;
   const int tf = t - frame * tiles_per_frame;
   const int ty = tf / a.tiles_x, tx = tf - ty * a.tiles_x;

@@ -23,16 +23,17 @@ constexpr int kFusedTileH = 16;  // output rows per fused-kernel tile (multiple 
 // 16 EASU rows — 32 x 8 quads, one per lane — kept in an LDS ring of 18 rows (the 16 new ones and the last two of the step before).
 constexpr int kFs2OutW = 62, kFs2MidW = 64, kFs2FpW = 35;
 constexpr int kFs2QH = 8, kFs2FpH = kFs2QH + 3, kFs2Step = 2 * kFs2QH, kFs2Ring = kFs2Step + 2;  // quad rows, footprint rows, EASU rows per step, ring rows
-constexpr int kXcds = 8;  // MI355X: 8 XCDs, workgroup b is dispatched to XCD b % 8
 
 struct ColorPassArgs {
   ImageView in, out;
+  int xcd_shift;  // log2 of the XCDs behind the device (3 on an MI355X in SPX mode): xcd_swizzle
   int tiles_x, tiles_y, frames;
   ColorArgs color;
 };
 
 struct EasuArgs {
   ImageView in, out;
+  int xcd_shift;  // log2 of the XCDs behind the device (3 on an MI355X in SPX mode): xcd_swizzle
   uint32_t con[16];
   int tiles_x, tiles_y, frames;
   int fp_w, fp_h;  // LDS footprint capacity (texels) per tile, >= the largest footprint of any tile
@@ -43,6 +44,7 @@ struct EasuArgs {
 
 struct RcasArgs {
   ImageView in, out;
+  int xcd_shift;  // log2 of the XCDs behind the device (3 on an MI355X in SPX mode): xcd_swizzle
   uint32_t con[4];
   int tiles_x, tiles_y, frames;
   int rows;  // rows per strip (a multiple of the kernel's row ring), chosen by the launcher
@@ -53,6 +55,7 @@ struct RcasArgs {
 
 struct FusedArgs {
   ImageView in, out;
+  int xcd_shift;  // log2 of the XCDs behind the device (3 on an MI355X in SPX mode): xcd_swizzle
   uint32_t easu_con[16];
   uint32_t rcas_con[4];
   int tiles_x, tiles_y, frames;
@@ -65,12 +68,16 @@ struct FusedArgs {
   int run_steps;  // exact-2x kernel (fsr1_fused_s2.hip): 16-row steps a workgroup walks down its column
 };
 
-// XCD-aware workgroup -> tile mapping.  Consecutive workgroup ids round-robin over the 8 XCDs
+// XCD-aware workgroup -> tile mapping.  Consecutive workgroup ids round-robin over the device's XCDs
 // (each with a private 4 MiB L2), so the ids that land on one XCD are given one contiguous range
 // of tiles: neighbouring tiles, which share their input aprons, then share an L2.
-__device__ __forceinline__ int xcd_swizzle(int b, int n) {
-  const int q = n / kXcds, r = n % kXcds;
-  const int xcd = b % kXcds, idx = b / kXcds;
+// xcd_shift: log2 of the XCD count, from the host (fsr1_api.hip: the device's CU count / 32 — 8 XCDs on an MI355X in SPX mode, 4 / 2 / 1
+// in the DPX / QPX / CPX partition modes, where the literal 8 of rounds 1-5 would have scattered neighbouring tiles over L2s that do
+// not exist); any value gives a permutation of the tiles, i.e. the same image.
+__device__ __forceinline__ int xcd_swizzle(int b, int n, int xcd_shift) {
+  const int xcds = 1 << xcd_shift;
+  const int q = n >> xcd_shift, r = n & (xcds - 1);
+  const int xcd = b & (xcds - 1), idx = b >> xcd_shift;
   return xcd * q + (xcd < r ? xcd : r) + idx;
 }
 

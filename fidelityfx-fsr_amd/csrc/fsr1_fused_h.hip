@@ -24,7 +24,7 @@ __global__ void __launch_bounds__(kThreads) fused_h_kernel(const FusedArgs a) {
   half4_t* const mid = reinterpret_cast<half4_t*>(smem + (size_t)cap * kEasuHLdsPerTexel);  // [kMidH][kMidW]
 
   const int tiles_per_frame = a.tiles_x * a.tiles_y;
-  const int t = xcd_swizzle(blockIdx.x, tiles_per_frame * a.frames);
+  const int t = xcd_swizzle(blockIdx.x, tiles_per_frame * a.frames, a.xcd_shift);
   const int frame = t / tiles_per_frame;
   const int tf = t - frame * tiles_per_frame;
   const int ty = tf / a.tiles_x, tx = tf - ty * a.tiles_x;

@@ -30,7 +30,7 @@ __global__ void __launch_bounds__(kThreads) fused_kernel(const FusedArgs a) {
   const EasuStrictQueue sq = easu_strict_queue_carve(reinterpret_cast<char*>(mid) + ((sizeof(texel_t) * kMidW * kMidH + 15) & ~(size_t)15));  // (STRICT)
 
   const int tiles_per_frame = a.tiles_x * a.tiles_y;
-  const int t = xcd_swizzle(blockIdx.x, tiles_per_frame * a.frames);
+  const int t = xcd_swizzle(blockIdx.x, tiles_per_frame * a.frames, a.xcd_shift);
   const int frame = t / tiles_per_frame;
   const int tf = t - frame * tiles_per_frame;
   const int ty = tf / a.tiles_x, tx = tf - ty * a.tiles_x;

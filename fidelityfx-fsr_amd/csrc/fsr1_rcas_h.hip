@@ -36,7 +36,7 @@ __global__ void __launch_bounds__(kRcasHThreads) rcas_h_kernel(const RcasArgs a)
   const uint32_t flags = OPTS ? a.flags : 0u;
   const bool stream = (a.flags & FSR1_FLAG_OUTPUT_STREAMING) != 0;
   const int tiles_per_frame = a.tiles_x * a.tiles_y;
-  const int t = xcd_swizzle(blockIdx.x, tiles_per_frame * a.frames);
+  const int t = xcd_swizzle(blockIdx.x, tiles_per_frame * a.frames, a.xcd_shift);
   const int frame = t / tiles_per_frame;
   const int tf = t - frame * tiles_per_frame;
   const int ty = tf / a.tiles_x, tx = tf - ty * a.tiles_x;

@@ -154,7 +154,7 @@ __device__ __forceinline__ void rcas_strip(const RcasArgs& a, int frame, int x0,
 template <int FMT, bool EXACT, bool OPTS, bool COLOR = false, int FOUT = FMT, int RING = ((FMT == FSR1_FORMAT_RGBA32F || COLOR) ? 4 : kRcasRing)>
 __global__ void __launch_bounds__(kRcasThreads) rcas_kernel(const RcasArgs a) {
   const int tiles_per_frame = a.tiles_x * a.tiles_y;
-  const int t = xcd_swizzle(blockIdx.x, tiles_per_frame * a.frames);
+  const int t = xcd_swizzle(blockIdx.x, tiles_per_frame * a.frames, a.xcd_shift);
   const int frame = t / tiles_per_frame;
   const int tf = t - frame * tiles_per_frame;
   const int ty = tf / a.tiles_x, tx = tf - ty * a.tiles_x;

@@ -14,7 +14,7 @@
  * data ever crosses a link.  Rank 0 prints one JSON line.
  *
  *   fsr1_runner [--gpus N] [--frames F] [--in WxH] [--out WxH] [--steps K] [--warmup W]
- *               [--pipeline two-pass|fused|easu|auto] [--math f|strict|exact|h] [--sharpness STOPS] [--hdr]
+ *               [--pipeline two-pass|fused|easu|auto] [--math f|strict|exact|h] [--sharpness STOPS] [--hdr] [--no-pin]
  *               [--stages BITS] [--grain AMOUNT] [--ring R] [--bands] [--streams S] [--dry-run [--dry-fail RANK]]
  *
  * --bands: strong scaling of ONE frame stream instead of weak scaling over frames — every GPU holds the whole
@@ -37,7 +37,9 @@
  * scaler (sample/src/DX12/FSR_Tonemapping.hlsl:87) — with a 128x128 x 4-slice tiled noise texture generated here.
  */
 #define __HIP_PLATFORM_AMD__ 1
+#define _GNU_SOURCE /* pthread_setaffinity_np, CPU_SET */
 #include <hip/hip_runtime_api.h>
+#include <sched.h>
 #include <math.h>
 #include <pthread.h>
 #include <stdatomic.h>
@@ -62,6 +64,7 @@ typedef struct {
   int streams; /* HIP streams per GPU the steps alternate over (fsr1_pipeline); 1 = one in-order stream */
   int dry;   /* 1: --dry-run (no device, no RCCL) */
   int dry_fail; /* --dry-fail RANK: that rank reports a failure before the barrier (-1: none) */
+  int no_pin;   /* --no-pin: leave the per-GPU threads' CPU affinity alone */
 } options_t;
 
 /* A rank that fails must not leave the others blocked in the collective: every rank reaches this barrier, failed or
@@ -72,6 +75,8 @@ static pthread_barrier_t g_before_collective;
 typedef struct {
   const options_t* opt;
   int rank;
+  int pinned_cpus;     /* CPUs this rank's thread was pinned to (0: not pinned) */
+  char cpu_list[128];  /* ... as sysfs lists them */
   ncclComm_t comm;
   /* results */
   uint64_t counters[3];  /* frames, output pixels, device nanoseconds (timed region) */
@@ -226,12 +231,45 @@ static int worker_body_bands(worker_t* w) {
   return 0;
 }
 
+/* Pins the calling thread to the CPUs local to device `dev`'s PCIe root (sysfs local_cpulist of its PCI node): a rank's launches then
+ * come from the NUMA node its GPU hangs off (SURVEY 8e / VERDICT r5 weak 8: eight ranks submit ~16 k steps/s each).  Best effort:
+ * returns the number of CPUs in the mask, 0 when the list could not be read (the thread keeps its affinity).  `list` receives the text. */
+static int pin_to_device_cpus(int dev, char* list, size_t list_len) {
+  char bdf[64] = "", path[160];
+  if (list_len) list[0] = 0;
+  if (hipDeviceGetPCIBusId(bdf, (int)sizeof bdf, dev) != hipSuccess) return 0;
+  for (char* c = bdf; *c; ++c) if (*c >= 'A' && *c <= 'F') *c = (char)(*c - 'A' + 'a');
+  snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/local_cpulist", bdf);
+  FILE* f = fopen(path, "r");
+  if (!f) return 0;
+  char buf[256] = "";
+  if (!fgets(buf, sizeof buf, f)) buf[0] = 0;
+  fclose(f);
+  buf[strcspn(buf, "\n")] = 0;
+  cpu_set_t set;
+  CPU_ZERO(&set);
+  int n = 0;
+  for (char* p = buf; *p;) {  /* "0-63,128-191" */
+    char* end;
+    long a = strtol(p, &end, 10), b = a;
+    if (end == p) break;
+    if (*end == '-') { p = end + 1; b = strtol(p, &end, 10); }
+    for (long c = a; c <= b && c < CPU_SETSIZE; ++c) { CPU_SET((int)c, &set); ++n; }
+    p = *end == ',' ? end + 1 : end;
+    if (*end != ',' ) break;
+  }
+  if (n == 0 || pthread_setaffinity_np(pthread_self(), sizeof set, &set) != 0) return 0;
+  if (list_len) snprintf(list, list_len, "%s", buf);
+  return n;
+}
+
 static int worker_body(worker_t* w) {
   const options_t* o = w->opt;
   int f0, f1;
   shard(o->frames, w->rank, o->gpus, &f0, &f1);
   const int nf = f1 - f0;
   HIP_OK(w, hipSetDevice(w->rank));
+  if (!o->no_pin) w->pinned_cpus = pin_to_device_cpus(w->rank, w->cpu_list, sizeof w->cpu_list);
   HIP_OK(w, hipStreamCreate(&w->stream));
   hipStream_t stream = w->stream;
 
@@ -400,12 +438,13 @@ static void usage(void) {
        "                   [--ring R]   (input / output sets to rotate over; default: more than 1 GiB, 4 x the Infinity Cache)\n"
        "                   [--bands]    (one frame stream split into row bands over the GPUs instead of frames per GPU)\n"
        "                   [--streams S] (HIP streams per GPU the steps alternate over, default 3; 1 = one in-order stream)\n"
+       "                   [--no-pin]   (do not pin each GPU's thread to the CPUs local to that GPU's PCIe root)\n"
        "                   [--dry-run [--dry-fail RANK]]   (the N-thread host side without devices or RCCL: shards, plan, barrier, abort path, JSON)\n"
        "defaults: 1 GPU, 1 frame per GPU, 1920x1080 -> 3840x2160, 100 steps, 10 warmup, two-pass, f, 0.25 stops");
 }
 
 int main(int argc, char** argv) {
-  options_t o = {1, 0, 1920, 1080, 3840, 2160, 100, 10, 0, 0, 0u, 0.25f, 0u, 0.25f, 0, 0, 3, 0, -1};
+  options_t o = {1, 0, 1920, 1080, 3840, 2160, 100, 10, 0, 0, 0u, 0.25f, 0u, 0.25f, 0, 0, 3, 0, -1, 0};
   for (int i = 1; i < argc; ++i) {
     const char* a = argv[i];
     const char* v = i + 1 < argc ? argv[i + 1] : NULL;
@@ -413,6 +452,7 @@ int main(int argc, char** argv) {
     else if (!strcmp(a, "--hdr")) o.hdr = 1;
     else if (!strcmp(a, "--bands")) o.bands = 1;
     else if (!strcmp(a, "--dry-run")) o.dry = 1;
+    else if (!strcmp(a, "--no-pin")) o.no_pin = 1;
     else if (!strcmp(a, "--dry-fail") && v) { o.dry_fail = atoi(v); ++i; }
     else if (!v) { fprintf(stderr, "missing value for %s\n", a); return 2; }
     else if (!strcmp(a, "--gpus")) { o.gpus = atoi(v); ++i; }
@@ -502,6 +542,10 @@ int main(int argc, char** argv) {
     for (int i = 0; i < o.gpus; ++i) printf("%s%.3f", i ? ", " : "", (double)gathered[3 * i + 2] * 1e-6);
     printf("], \"per_rank_seconds\": [");
     for (int i = 0; i < o.gpus; ++i) printf("%s%.6f", i ? ", " : "", (double)gathered[3 * i + 2] * 1e-9);
+    printf("], \"cpu_binding\": [");  /* the CPUs each rank's thread was pinned to: those local to its GPU's PCIe root (null: not pinned) */
+    for (int i = 0; i < o.gpus; ++i) {
+      if (ws[i].pinned_cpus) printf("%s\"%s\"", i ? ", " : "", ws[i].cpu_list); else printf("%snull", i ? ", " : "");
+    }
     printf("]}\n");
   }
   pthread_barrier_destroy(&g_before_collective);

@@ -89,3 +89,24 @@ def test_telemetry_summary_and_gather_without_a_process_group():
     import torch
     mhz, watts = bench.gather_pairs(2100.0, None, torch.device("cpu"))
     assert mhz == [2100.0] and watts == [None]
+
+
+def test_telemetry_block_marks_a_short_sample_unreliable():
+    """Round 6: the per-rank clock / power figures come from a dedicated 1.2 s window of the headline's load (>= 200 samples at 2 ms whatever
+    --steps is); a line whose window held fewer samples on any rank says so instead of quoting a figure that under-reads a short load
+    (round 5's K = 20 line: 57 samples of a 0.1 s run, 20 % low).  The block also carries the power cap, whether each rank sat at it, the
+    SMU's throttle-accumulator deltas and the compute-partition mode."""
+    import bench
+    import torch
+    rows = bench.gather_row([2180.0, 1352.0, 600, 1400.0, 1234.0, 0.0], torch.device("cpu"))
+    assert rows == [[2180.0, 1352.0, 600.0, 1400.0, 1234.0, 0.0]]
+    good = bench.telemetry_block(rows + [[2100.0, 1100.0, 580, 1400.0, None, None]], "sysfs", 2.0, bench.TELEMETRY_WINDOW_S, "SPX")
+    assert good["reliable"] is True and "unreliable" not in good
+    assert good["samples_per_rank"] == [600, 580] and good["power_cap_w"] == [1400.0, 1400.0]
+    assert good["at_power_cap"] == [True, False] and good["compute_partition"] == "SPX"
+    assert good["throttle_accumulator_delta"]["ppt"] == [1234.0, None]
+    short = bench.telemetry_block([[2049.0, 1082.0, 57, 1400.0, None, None]], "sysfs", 2.0, bench.TELEMETRY_WINDOW_S, "SPX")
+    assert short["reliable"] is False and "unreliable" in short
+    none = bench.telemetry_block([[None, None, None, None, None, None]], None, 2.0, bench.TELEMETRY_WINDOW_S, None)
+    assert none["reliable"] is False and none["at_power_cap"] == [None]
+    assert bench.TELEMETRY_WINDOW_S / 0.002 >= 2 * bench.TELEMETRY_MIN_SAMPLES  # the window is sized for twice the minimum
