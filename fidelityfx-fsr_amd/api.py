@@ -373,6 +373,9 @@ class Pipeline:
         of `src`, the last consumer of `dst`) — one event, one wait, on that slot's stream only;
       * lifetime: src / dst / stages stay referenced until the submission has left the device (or join() / synchronize() / close()),
         so torch's caching allocator cannot hand their memory to a later op on the current stream while a pipeline kernel still uses it.
+    Cost of managed = True per upscale(): one event record + one stream wait in front and one event record behind, per slot used (every
+    slot for a batch: the wrapper cannot know which slots the library's frame-by-frame split takes), plus the completion queries of
+    the oldest submissions — a few microseconds of host time; a loop that needs the last of them uses managed = False (bench.py does).
     join() (or synchronize()) is still mandatory before the OUTPUTS are consumed on a torch stream.  managed = False is the bare C
     ABI: the caller forks, joins and keeps tensors alive itself (bench.py: its buffers live for the whole run and it synchronizes
     around every timed region).
@@ -422,18 +425,24 @@ class Pipeline:
                 st.wait_stream(torch.cuda.current_stream())
         _lib.check(_lib.load().fsr1_pipeline_upscale(self._h, ctypes.byref(i), ctypes.byref(o), ctypes.byref(p), sp))
         if self.managed and not torch.cuda.is_current_stream_capturing():  # (a captured submission runs at replay time: the graph's owner keeps its tensors)
-            while self._live and all(e.query() for e in self._live[0][0]):  # submissions that have left the device no longer need their tensors held
-                self._live.pop(0)
+            self._trim()  # submissions that have left the device no longer need their tensors held
             self._live.append(([st.record_event() for st in used], (src, dst, stages)))
         return dst
 
     def fork(self, stream=None):
         _lib.check(_lib.load().fsr1_pipeline_fork(self._h, _stream_ptr(stream)))
 
+    def _trim(self):
+        """Drops the references of submissions that have left the device."""
+        while self._live and all(e.query() for e in self._live[0][0]):
+            self._live.pop(0)
+
     def join(self, stream=None):
         """Work submitted to `stream` (default: the current torch stream) afterwards starts only after everything the pipeline holds now.
-        (The tensors of finished submissions are released as later calls notice their completion, or by synchronize() / close().)"""
+        The tensors of submissions that have already finished are released here as well (and by later upscale() calls, synchronize(),
+        close()); the ones still in flight stay referenced until one of those notices their completion."""
         _lib.check(_lib.load().fsr1_pipeline_join(self._h, _stream_ptr(stream)))
+        self._trim()
 
     def synchronize(self):
         _lib.check(_lib.load().fsr1_pipeline_synchronize(self._h))

@@ -15,7 +15,7 @@ namespace fsr1 {
 hipError_t easu_launch(const EasuArgs& a, int fmt, bool exact, bool s2, bool tall, hipStream_t stream, bool strict);
 size_t easu_strict_lds_bytes(int fmt, int fp_w, int fp_h, int tile_h);
 bool easu_s2_tall_tiles(int width, int height, int frames, bool overlapped, int cus);
-bool easu_generic_tall_tiles(int width, int height, int frames, int cus, size_t lds_tall);
+bool easu_generic_tall_tiles(int width, int height, int frames, int cus, size_t lds_tall, size_t lds_per_cu);
 int easu_lds_pitch(int fp_w, bool exact, bool color);
 size_t easu_lds_bytes(int fmt, int fp_w, int fp_h);
 hipError_t rcas_launch(const RcasArgs& a, int fmt, bool exact, hipStream_t stream);
@@ -260,6 +260,27 @@ static int device_cus() {
   return cus;
 }
 
+// The last-level cache in front of HBM ("Infinity Cache", 256 MB on MI355X) as HIP reports it (hipDeviceAttributeL2CacheSize is the
+// per-XCD L2; the memory-side cache has no attribute of its own in this runtime): a constant for this family, in ONE place — the batch
+// split of fsr1_pipeline_upscale and the store policy of the EASU intermediary compare sizes with it.
+static size_t infinity_cache_bytes() { return (size_t)256 << 20; }
+
+// LDS bytes a CU offers its resident workgroups (160 KB on gfx950), read from the device once instead of assumed: the
+// launch rules that count workgroups per CU by their LDS (easu_generic_tall_tiles) and the "does it fit at all" checks use it.
+static size_t device_lds_per_cu() {
+  constexpr int kDevices = 64;
+  static std::atomic<int> cache[kDevices];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 160 * 1024;
+  if (dev >= 0 && dev < kDevices) {
+    if (const int c = cache[dev].load(std::memory_order_relaxed); c > 0) return (size_t)c;
+  }
+  int bytes = 0;
+  if (hipDeviceGetAttribute(&bytes, hipDeviceAttributeMaxSharedMemoryPerMultiprocessor, dev) != hipSuccess || bytes < 64 * 1024) bytes = 160 * 1024;
+  if (dev >= 0 && dev < kDevices) cache[dev].store(bytes, std::memory_order_relaxed);
+  return (size_t)bytes;
+}
+
 // log2 of the XCDs behind the current device, for the kernels' workgroup -> tile mapping (xcd_swizzle): an XCD of this family has 32 CUs
 // (MI355X: 256 CUs = 8 XCDs in SPX mode; the DPX / QPX / CPX partition modes expose devices of 128 / 64 / 32 CUs).  A CU count that is
 // not 32 x a power of two (another part) rounds down: any value only permutes the tiles.
@@ -289,7 +310,7 @@ static bool auto_takes_fused(const fsr1_image* in, bool have_intermediary, const
     memcpy(&by, &easu_con[3], 4);
     const int fp_w = footprint_extent(out->width, kTileW, 1, sx, bx), fp_h = footprint_extent(out->height, kFusedTileH, 1, sy, by);
     if (fp_w < 0 || fp_h < 0) return false;
-    if ((packed ? fused_h_lds_bytes(fp_w, fp_h) : fused_lds_bytes(in->format, fp_w, fp_h)) > 160 * 1024) return false;
+    if ((packed ? fused_h_lds_bytes(fp_w, fp_h) : fused_lds_bytes(in->format, fp_w, fp_h)) > device_lds_per_cu()) return false;
   }
   const long long out_pixels = (long long)out->width * (long long)out->height * (long long)out->frames;
   // Packed fp16 at exactly 2x has a quad-form fused launch of its own (fsr1_fused_s2_h.hip, round 4) that walks longer runs the larger
@@ -368,10 +389,10 @@ static int easu_dispatch_impl(const fsr1_image* in, const fsr1_image* out, const
   a.fp_w = footprint_extent(out->width, kTileW, 0, sx, bx, origin_x);
   a.fp_h = footprint_extent(out->height, kTileH, 0, sy, by, origin_y);
   if (a.fp_w < 0 || a.fp_h < 0) return fail(FSR1_ERR_INVALID_ARGUMENT, "easu: scale constants con0.xy = (%g, %g) are not usable", sx, sy);
-  if (easu_lds_bytes(in->format, a.fp_w, a.fp_h) > 160 * 1024)
+  if (easu_lds_bytes(in->format, a.fp_w, a.fp_h) > device_lds_per_cu())
     return fail(FSR1_ERR_UNSUPPORTED, "easu: input/output ratio (%g, %g) needs a %dx%d texel footprint per tile, beyond the LDS budget "
                                       "(EASU is an upscaler; ratios up to ~3x minification are supported)", sx, sy, a.fp_w, a.fp_h);
-  if ((flags & FSR1_FLAG_MATH_STRICT) && easu_strict_lds_bytes(in->format, a.fp_w, a.fp_h, kTileH) > 160 * 1024)  // (no room for the queue: EXACT)
+  if ((flags & FSR1_FLAG_MATH_STRICT) && easu_strict_lds_bytes(in->format, a.fp_w, a.fp_h, kTileH) > device_lds_per_cu())  // (no room for the queue: EXACT)
     flags = (flags & ~(uint32_t)FSR1_FLAG_MATH_STRICT) | FSR1_FLAG_MATH_EXACT;
   const bool strict = (flags & FSR1_FLAG_MATH_STRICT) != 0;
   if ((long long)(a.fp_h + 1) * a.in.pitch >= (1ll << 31))  // staging addresses texels as row base + 32-bit offset
@@ -382,7 +403,7 @@ static int easu_dispatch_impl(const fsr1_image* in, const fsr1_image* out, const
   // RCAS normally follows: keep the intermediary cached — unless it is far larger than the 256 MB Infinity Cache anyway (batches):
   // then plain stores only leave dirty lines for the kernel's end to write back (round 4, 8-frame 1440p -> 4K batch, 531 MB: two
   // dispatches 610-613 -> 600-605 us; one 4K frame, 66 MB, the other way: 65.8 -> 70.5; profiles/ab_r04/r4c17_easu_streaming_stores.log)
-  const bool beyond_cache = (unsigned long long)a.out.pitch * (unsigned long long)out->height * (unsigned long long)out->frames > (512ull << 20);
+  const bool beyond_cache = (unsigned long long)a.out.pitch * (unsigned long long)out->height * (unsigned long long)out->frames > 2 * (unsigned long long)infinity_cache_bytes();
   a.flags = resolve_output_policy(flags, beyond_cache);
   // Exact 2x with the viewport covering the input — con0 = {1/2, 1/2, -1/4, -1/4}, what FsrEasuCon gives for
   // out = 2 * in — takes the variant whose lanes own 2x2 output quads; its tiles are shifted by one pixel, hence one
@@ -399,7 +420,7 @@ static int easu_dispatch_impl(const fsr1_image* in, const fsr1_image* out, const
     const int pitch = easu_lds_pitch(a.fp_w, false, false);
     if (fp_h32 > 0 && pitch &&
         easu_generic_tall_tiles(out->width, out->height, out->frames, device_cus(),
-                                strict ? easu_strict_lds_bytes(in->format, pitch, fp_h32, 2 * kTileH) : easu_lds_bytes(in->format, pitch, fp_h32)) &&
+                                strict ? easu_strict_lds_bytes(in->format, pitch, fp_h32, 2 * kTileH) : easu_lds_bytes(in->format, pitch, fp_h32), device_lds_per_cu()) &&
         (long long)(fp_h32 + 1) * a.in.pitch < (1ll << 31)) {
       tall = true;
       a.fp_h = fp_h32;
@@ -562,7 +583,7 @@ static int fused_dispatch_impl(const fsr1_image* in, const fsr1_image* out, cons
   a.rows_below = rows_below;
   if (a.fp_w < 0 || a.fp_h < 0) return fail(FSR1_ERR_INVALID_ARGUMENT, "fused: scale constants con0.xy = (%g, %g) are not usable", sx, sy);
   const bool strict = (flags & FSR1_FLAG_MATH_STRICT) != 0;
-  if ((packed ? fused_h_lds_bytes(a.fp_w, a.fp_h) : strict ? fused_strict_lds_bytes(in->format, a.fp_w, a.fp_h) : fused_lds_bytes(in->format, a.fp_w, a.fp_h)) > 160 * 1024)
+  if ((packed ? fused_h_lds_bytes(a.fp_w, a.fp_h) : strict ? fused_strict_lds_bytes(in->format, a.fp_w, a.fp_h) : fused_lds_bytes(in->format, a.fp_w, a.fp_h)) > device_lds_per_cu())
     return fail(FSR1_ERR_UNSUPPORTED, "fused: input/output ratio (%g, %g) needs more LDS than a CU has", sx, sy);
   if ((long long)(a.fp_h + 1) * a.in.pitch >= (1ll << 31))
     return fail(FSR1_ERR_UNSUPPORTED, "fused: input row pitch %lld too large for a %d-row footprint", a.in.pitch, a.fp_h);
@@ -574,7 +595,7 @@ static int fused_dispatch_impl(const fsr1_image* in, const fsr1_image* out, cons
   // (packed fp16: the H twin, fsr1_fused_s2_h.hip — whole images only, five workgroups per CU)
   const bool s2 = easu_con[0] == 0x3f000000u && easu_con[1] == 0x3f000000u && easu_con[2] == 0xbe800000u && easu_con[3] == 0xbe800000u &&
                   !(flags & FSR1_FLAG_NO_FAST_PATHS) && !a.color.stages && !(origin_y & 1) &&
-                  (packed ? origin_y == 0 && !rows_above && !rows_below : fused_s2_lds_bytes(in->format, 4) <= 160 * 1024);
+                  (packed ? origin_y == 0 && !rows_above && !rows_below : fused_s2_lds_bytes(in->format, 4) <= device_lds_per_cu());
   a.run_steps = s2 ? fused_s2_run_steps(out->width, out->height, out->frames, device_cus(), packed ? 5 : 7, (flags & FSR1_FLAG_FRAMES_OVERLAP) != 0, strict) : 0;
   // F-strict: every step ends with the re-evaluation of its queued pixels by the workgroup's first lanes while the other waves wait at
   // the barrier in front of the RCAS phase — the fewer waves wait and the fewer steps serialise it, the better: 256-thread tiles, runs
@@ -677,7 +698,7 @@ static int upscale_decide(const char* who, const fsr1_image* in, bool have_inter
   if (fp_w < 0 || fp_h < 0) return fail(FSR1_ERR_INVALID_ARGUMENT, "%s: scale constants con0.xy = (%g, %g) are not usable", who, sx, sy);
   const bool packed = (plan->math & FSR1_FLAG_MATH_PACKED_FP16) != 0;
   if (!p->use_rcas || p->fused != 1) {  // an EASU dispatch will run (alone, or as the first of two, or as what `auto` may pick)
-    if (easu_lds_bytes(in->format, fp_w, fp_h) > 160 * 1024)
+    if (easu_lds_bytes(in->format, fp_w, fp_h) > device_lds_per_cu())
       return fail(FSR1_ERR_UNSUPPORTED, "%s: input/output ratio (%g, %g) needs a %dx%d texel footprint per tile, beyond the LDS budget", who, sx, sy, fp_w, fp_h);
   }
   if (!p->use_rcas) {
@@ -691,7 +712,7 @@ static int upscale_decide(const char* who, const fsr1_image* in, bool have_inter
   if (!fused && !have_intermediary) return fail(FSR1_ERR_INVALID_ARGUMENT, "%s: two-pass EASU+RCAS needs an intermediary image", who);
   if (fused) {  // the fused launch's own LDS bound (fused_dispatch_impl)
     const int ffw = footprint_extent(out->width, kTileW, 1, sx, bx), ffh = footprint_extent(out->height, kFusedTileH, 1, sy, by);
-    if (ffw < 0 || ffh < 0 || (packed ? fused_h_lds_bytes(ffw, ffh) : fused_lds_bytes(in->format, ffw, ffh)) > 160 * 1024)
+    if (ffw < 0 || ffh < 0 || (packed ? fused_h_lds_bytes(ffw, ffh) : fused_lds_bytes(in->format, ffw, ffh)) > device_lds_per_cu())
       return fail(FSR1_ERR_UNSUPPORTED, "%s: input/output ratio (%g, %g) needs more LDS than a CU has for the fused launch", who, sx, sy);
   }
   plan->pipeline = fused ? 1 : 0;
@@ -764,6 +785,7 @@ struct fsr1_pipeline {
   hipEvent_t fork_ev = nullptr;
   void* mid[kMax] = {};         // per-slot EASU -> RCAS intermediary, tightly packed, grown on demand
   size_t mid_bytes[kMax] = {};
+  bool stream_ordered_alloc = true;  // hipMallocAsync / hipFreeAsync available (hipDeviceAttributeMemoryPoolsSupported)
 };
 
 int fsr1_pipeline_create(fsr1_pipeline** out, int32_t streams) {
@@ -771,6 +793,10 @@ int fsr1_pipeline_create(fsr1_pipeline** out, int32_t streams) {
   if (streams < 1 || streams > fsr1_pipeline::kMax) return fail(FSR1_ERR_INVALID_ARGUMENT, "pipeline_create: streams must be 1 .. %d", fsr1_pipeline::kMax);
   fsr1_pipeline* p = new fsr1_pipeline;
   hipError_t e = hipGetDevice(&p->device);
+  if (e == hipSuccess) {  // stream-ordered growth of the intermediaries needs the device's memory pools; without them: hipMalloc + a stream sync
+    int pools = 0;
+    p->stream_ordered_alloc = hipDeviceGetAttribute(&pools, hipDeviceAttributeMemoryPoolsSupported, p->device) == hipSuccess && pools != 0;
+  }
   if (e == hipSuccess) e = hipEventCreateWithFlags(&p->fork_ev, hipEventDisableTiming);
   for (int i = 0; i < streams && e == hipSuccess; ++i) {
     e = hipStreamCreateWithFlags(&p->streams[i], hipStreamNonBlocking);
@@ -788,7 +814,8 @@ int fsr1_pipeline_create(fsr1_pipeline** out, int32_t streams) {
 
 // Grows slot `slot`'s intermediary to at least `need` bytes, in stream order on the slot's own stream (hipFreeAsync / hipMallocAsync:
 // no host block, no device-wide synchronisation; the old buffer is released after the slot's last submission, the new one exists
-// before its next).  Refused with a clear error while the stream is being captured into a hipGraph: an allocation node inside a
+// before its next).  A hipGraph captured EARLIER keeps the old pointer: any later growth invalidates it (include/fsr1_hip.h) — reserve the
+// largest size before the first capture.  Refused with a clear error while the stream is being captured into a hipGraph: an allocation node inside a
 // captured frame is not what the caller wants replayed — fsr1_pipeline_reserve() before the capture instead.
 static int pipeline_grow(fsr1_pipeline* p, int slot, size_t need, const char* who) {
   if (p->mid_bytes[slot] >= need) return FSR1_OK;
@@ -797,6 +824,16 @@ static int pipeline_grow(fsr1_pipeline* p, int slot, size_t need, const char* wh
   if (cap != hipStreamCaptureStatusNone)
     return fail(FSR1_ERR_INVALID_ARGUMENT, "%s: stream %d's intermediary (%zu bytes) must grow to %zu bytes while the stream is being captured; "
                 "call fsr1_pipeline_reserve(pipeline, %zu) before the capture begins", who, slot, p->mid_bytes[slot], need, need);
+  if (!p->stream_ordered_alloc) {
+    // no memory pools on this device: the slot's stream drains, then a plain free / allocation (a host block, on growth only)
+    if (hipError_t e = hipStreamSynchronize(p->streams[slot]); e != hipSuccess) return hip_fail(e, "hipStreamSynchronize before growing the intermediary");
+    if (p->mid[slot]) (void)hipFree(p->mid[slot]);
+    p->mid[slot] = nullptr;
+    p->mid_bytes[slot] = 0;
+    if (hipError_t e = hipMalloc(&p->mid[slot], need); e != hipSuccess) return hip_fail(e, "hipMalloc of the intermediary");
+    p->mid_bytes[slot] = need;
+    return FSR1_OK;
+  }
   if (p->mid[slot]) {
     if (hipError_t e = hipFreeAsync(p->mid[slot], p->streams[slot]); e != hipSuccess) return hip_fail(e, "hipFreeAsync of the intermediary");
     p->mid[slot] = nullptr;
@@ -832,17 +869,35 @@ int fsr1_pipeline_upscale(fsr1_pipeline* p, const fsr1_image* in, const fsr1_ima
   // runs on slot (next_slot + f) mod N; the frames are the same kernels on the same values as in one launch: bit-identical
   // (tests/test_gpu_pipeline.py).  8K frames (265 MB each) and fused launches keep the single launch.
   if (plan.pipeline == 0 && out->frames > 1 && p->n > 1 &&
-      (size_t)out->width * pixel_bytes(out->format) * (size_t)out->height * (size_t)p->n <= ((size_t)256 << 20)) {
+      (size_t)out->width * pixel_bytes(out->format) * (size_t)out->height * (size_t)p->n <= infinity_cache_bytes()) {
     ImageView vi, vo;
     if (int rc = check_image(in, "pipeline_upscale input", &vi)) return rc;
     if (int rc = check_image(out, "pipeline_upscale output", &vo)) return rc;
+    if (overlaps(in, vi, out, vo)) return fail(FSR1_ERR_INVALID_ARGUMENT, "pipeline_upscale: input and output overlap");
+    // every frame runs what was decided for the BATCH (decided again per frame, `auto` could take the fused launch for single
+    // frames of a batch planned as two dispatches): the per-frame calls carry fused = 0
+    fsr1_params per_frame = *params;
+    per_frame.fused = 0;
+    {  // everything a per-frame call could refuse is refused here, before frame 0 is submitted (the frames differ only in their base pointers)
+      fsr1_image fi = *in, fo = *out;
+      fi.frames = fo.frames = 1;
+      fi.frame_stride_bytes = fo.frame_stride_bytes = 0;
+      UpscalePlan one;
+      if (int rc = upscale_decide("pipeline_upscale (frame of a batch)", &fi, true, &fo, &per_frame, stages != nullptr, &one)) return rc;
+      if (one.pipeline != 0) return fail(FSR1_ERR_INVALID_ARGUMENT, "pipeline_upscale: a frame of a two-dispatch batch planned as pipeline %d", one.pipeline);
+    }
     for (int f = 0; f < out->frames; ++f) {
       fsr1_image fi = *in, fo = *out;
       fi.data = vi.base + (long long)f * vi.frame_stride;
       fo.data = vo.base + (long long)f * vo.frame_stride;
       fi.frames = fo.frames = 1;
       fi.frame_stride_bytes = fo.frame_stride_bytes = 0;
-      if (int rc = fsr1_pipeline_upscale(p, &fi, &fo, params, stages)) return rc;
+      if (int rc = fsr1_pipeline_upscale(p, &fi, &fo, &per_frame, stages)) {
+        // (a HIP failure mid-batch: frames 0 .. f-1 are submitted and the slot counter has advanced by f — say so)
+        char first[384];
+        snprintf(first, sizeof first, "%s", g_err);
+        return fail(rc, "pipeline_upscale: frame %d of %d failed after %d frame(s) were submitted (next slot %d): %s", f, out->frames, f, p->next, first);
+      }
     }
     return FSR1_OK;
   }

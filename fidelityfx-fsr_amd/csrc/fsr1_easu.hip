@@ -57,11 +57,12 @@ bool easu_s2_tall_tiles(int width, int height, int frames, bool overlapped, int 
 
 // The generic kernel (default arithmetic, pitched LDS layout) on 64 x 32 tiles with 512-thread workgroups (easu_kernel<..., WAVES = 8>):
 // whenever the taller footprint still lets a CU hold three workgroups (24 waves) and the launch has at least two workgroups per CU.
-// `lds_tall`: bytes of the 32-row tile's footprint in the pitched layout.
-bool easu_generic_tall_tiles(int width, int height, int frames, int cus, size_t lds_tall) {
-  if (const int forced = override_easu_s2_tall(); forced >= 0) return forced != 0 && lds_tall <= 160 * 1024;  // (test library only)
+// `lds_tall`: bytes of the 32-row tile's footprint in the pitched layout; `lds_per_cu`: what a CU offers (hipDeviceAttributeMaxSharedMemoryPerMultiprocessor).
+bool easu_generic_tall_tiles(int width, int height, int frames, int cus, size_t lds_tall, size_t lds_per_cu) {
+  // (the test library's one tile-shape hook, fsr1_debug_easu_tall_tiles, forces BOTH this rule and easu_s2_tall_tiles: include/fsr1_hip_test.h)
+  if (const int forced = override_easu_s2_tall(); forced >= 0) return forced != 0 && lds_tall <= lds_per_cu;
   const long long tiles32 = (long long)((width + kTileW - 1) / kTileW) * ((height + 31) / 32) * frames;
-  return lds_tall * 3 <= 160 * 1024 && tiles32 >= 2ll * (cus > 0 ? cus : 256);
+  return lds_tall * 3 <= lds_per_cu && tiles32 >= 2ll * (cus > 0 ? cus : 256);
 }
 
 // s2: launch the exact-2x variant (the caller has checked con0 and laid the grid out for the shifted tiles); tall: on 64 x 32 tiles

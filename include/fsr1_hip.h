@@ -327,7 +327,12 @@ int fsr1_pipeline_create(fsr1_pipeline** pipeline, int32_t streams /* 1 .. 8 */)
  * the same pixels (round 5); larger frames and fused launches stay one launch on one slot.  Asynchronous: when the slot's intermediary is too small it is
  * re-allocated in stream order on the slot's own stream (hipFreeAsync / hipMallocAsync — no host block, no device-wide
  * synchronisation).  While the stream is being captured into a hipGraph a growth is refused with FSR1_ERR_INVALID_ARGUMENT and a
- * message naming the size to reserve: call fsr1_pipeline_reserve before the capture. */
+ * message naming the size to reserve: call fsr1_pipeline_reserve before the capture.  A hipGraph captured EARLIER holds the
+ * intermediary's address of that time: any later growth of the slot frees that buffer and INVALIDATES the graph (replaying it would
+ * write into memory the pool may have handed to another slot) — reserve the largest size the pipeline will ever see before the first
+ * capture.  On a device without memory pools (hipDeviceAttributeMemoryPoolsSupported == 0) a growth drains the slot's stream and uses
+ * hipFree / hipMalloc instead.  Every frame of a split batch runs what was decided for the batch (two dispatches); all arguments are
+ * validated before frame 0 is submitted, and if a HIP call fails mid-batch the error message says how many frames were submitted. */
 int fsr1_pipeline_upscale(fsr1_pipeline* pipeline, const fsr1_image* in, const fsr1_image* out, const fsr1_params* params,
                           const fsr1_color_stages* stages);
 /* Pre-sizes every slot's intermediary to at least bytes_per_stream (= out width x height x bytes per pixel of the largest frame the

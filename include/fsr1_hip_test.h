@@ -23,7 +23,10 @@ void fsr1_debug_fused_run_steps(int32_t steps);
 /* Tile shape of its one-step launches: -1 = the host's rule (the 62 x 30 tile of a 512-thread workgroup for frames that fill the
  * chip, the 62 x 14 tile of a 256-thread one otherwise), 0 = never the tall tile, 1 = always. */
 void fsr1_debug_fused_tall_tiles(int32_t mode);
-/* ... and of exact-2x EASU launches (F arithmetic): 64 x 32 tiles for large or overlapped launches, 64 x 16 otherwise; -1 / 0 / 1 as above. */
+/* ... and of the EASU launches (F arithmetic, F-strict included), BOTH rules at once: exact 2x — 64 x 32 tiles for large or overlapped launches,
+ * 64 x 16 otherwise (easu_s2_tall_tiles) — and any other ratio — the 512-thread workgroup on 64 x 32 tiles where its footprint leaves three
+ * workgroups per CU, the 256-thread one on 64 x 16 otherwise (easu_generic_tall_tiles); -1 / 0 / 1 as above (1 is still refused where the
+ * 32-row footprint does not fit a CU's LDS at all). */
 void fsr1_debug_easu_tall_tiles(int32_t mode);
 
 #ifdef __cplusplus

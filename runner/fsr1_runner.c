@@ -65,6 +65,7 @@ typedef struct {
   int dry;   /* 1: --dry-run (no device, no RCCL) */
   int dry_fail; /* --dry-fail RANK: that rank reports a failure before the barrier (-1: none) */
   int no_pin;   /* --no-pin: leave the per-GPU threads' CPU affinity alone */
+  int latency;  /* --latency N: after the throughput run, N single frames with 1 ms of idle GPU before each: submit -> hipStreamSynchronize, host clock */
 } options_t;
 
 /* A rank that fails must not leave the others blocked in the collective: every rank reaches this barrier, failed or
@@ -76,6 +77,7 @@ typedef struct {
   const options_t* opt;
   int rank;
   int pinned_cpus;     /* CPUs this rank's thread was pinned to (0: not pinned) */
+  double lat_med_us, lat_p90_us, lat_b2b_us;  /* --latency: median / p90 after 1 ms idle, median back to back */
   char cpu_list[128];  /* ... as sysfs lists them */
   ncclComm_t comm;
   /* results */
@@ -362,6 +364,42 @@ static int worker_body(worker_t* w) {
     HIP_OK(w, hipEventSynchronize(w->ev1));
     HIP_OK(w, hipEventElapsedTime(&ms, w->ev0, w->ev1));
   }
+  if (o->latency > 0 && nf > 0) {
+    /* Single-frame latency from a C host (the reference's actual usage: one Upscale per display refresh, SampleRenderer.cpp:705-709): the
+     * host clock around fsr1_upscale_ex + hipStreamSynchronize on one stream, the GPU idle for 1 ms before every frame (it drops its
+     * clock within that time), then the same back to back.  bench.py's latency_us goes through Python / ctypes, which adds ~10 us of
+     * submission time per frame (profiles/ab_r06/r06_latency_probe.json). */
+    void* lmid = NULL;
+    if (needs_mid) HIP_OK(w, hipMalloc(&lmid, out_frame * nf));
+    const int n = o->latency, lead = 20;
+    double* t = (double*)malloc(sizeof(double) * (size_t)n);
+    if (!t) { snprintf(w->error, sizeof w->error, "out of host memory"); w->status = -1; return -1; }
+    for (int pass = 0; pass < 2; ++pass) {
+      for (int i = -lead; i < n; ++i) {
+        const size_t s = (size_t)((i + lead) % ring) * (size_t)nf;
+        fsr1_image in = {(char*)w->d_in + in_frame * s, o->in_w, o->in_h, FSR1_FORMAT_RGBA16F, nf, 0, 0};
+        fsr1_image mid = {lmid, o->out_w, o->out_h, FSR1_FORMAT_RGBA16F, nf, 0, 0};
+        fsr1_image out = {(char*)w->d_out + out_frame * s, o->out_w, o->out_h, FSR1_FORMAT_RGBA16F, nf, 0, 0};
+        if (pass == 0) { struct timespec idle = {0, 1000000}; nanosleep(&idle, NULL); }
+        struct timespec a, b;
+        clock_gettime(CLOCK_MONOTONIC, &a);
+        FSR_OK(w, fsr1_upscale_ex(&in, lmid ? &mid : NULL, &out, &p, &stages, stream));
+        HIP_OK(w, hipStreamSynchronize(stream));
+        clock_gettime(CLOCK_MONOTONIC, &b);
+        if (i >= 0) t[i] = (double)(b.tv_sec - a.tv_sec) * 1e6 + (double)(b.tv_nsec - a.tv_nsec) * 1e-3;
+      }
+      for (int i = 1; i < n; ++i) {  /* insertion sort: n is a few hundred */
+        const double v = t[i];
+        int j = i - 1;
+        for (; j >= 0 && t[j] > v; --j) t[j + 1] = t[j];
+        t[j + 1] = v;
+      }
+      if (pass == 0) { w->lat_med_us = t[n / 2]; w->lat_p90_us = t[(int)(0.9 * (n - 1))]; }
+      else w->lat_b2b_us = t[n / 2];
+    }
+    free(t);
+    if (lmid) (void)hipFree(lmid);
+  }
   w->counters[0] = (uint64_t)nf * (uint64_t)o->steps;
   w->counters[1] = w->counters[0] * (uint64_t)o->out_w * (uint64_t)o->out_h;
   w->counters[2] = (uint64_t)((double)ms * 1e6);
@@ -438,13 +476,14 @@ static void usage(void) {
        "                   [--ring R]   (input / output sets to rotate over; default: more than 1 GiB, 4 x the Infinity Cache)\n"
        "                   [--bands]    (one frame stream split into row bands over the GPUs instead of frames per GPU)\n"
        "                   [--streams S] (HIP streams per GPU the steps alternate over, default 3; 1 = one in-order stream)\n"
+       "                   [--latency N]   (after the run: N single frames, 1 ms of idle GPU before each, submit -> hipStreamSynchronize, host clock)\n"
        "                   [--no-pin]   (do not pin each GPU's thread to the CPUs local to that GPU's PCIe root)\n"
        "                   [--dry-run [--dry-fail RANK]]   (the N-thread host side without devices or RCCL: shards, plan, barrier, abort path, JSON)\n"
        "defaults: 1 GPU, 1 frame per GPU, 1920x1080 -> 3840x2160, 100 steps, 10 warmup, two-pass, f, 0.25 stops");
 }
 
 int main(int argc, char** argv) {
-  options_t o = {1, 0, 1920, 1080, 3840, 2160, 100, 10, 0, 0, 0u, 0.25f, 0u, 0.25f, 0, 0, 3, 0, -1, 0};
+  options_t o = {1, 0, 1920, 1080, 3840, 2160, 100, 10, 0, 0, 0u, 0.25f, 0u, 0.25f, 0, 0, 3, 0, -1, 0, 0};
   for (int i = 1; i < argc; ++i) {
     const char* a = argv[i];
     const char* v = i + 1 < argc ? argv[i + 1] : NULL;
@@ -463,6 +502,7 @@ int main(int argc, char** argv) {
     else if (!strcmp(a, "--stages")) { o.stages = (uint32_t)strtoul(v, NULL, 0); ++i; }
     else if (!strcmp(a, "--grain")) { o.grain = (float)atof(v); ++i; }
     else if (!strcmp(a, "--ring")) { o.ring = atoi(v); ++i; }
+    else if (!strcmp(a, "--latency")) { o.latency = atoi(v); ++i; }
     else if (!strcmp(a, "--streams")) { o.streams = atoi(v); ++i; }
     else if (!strcmp(a, "--in")) { if (!parse_size(v, &o.in_w, &o.in_h)) { fprintf(stderr, "bad --in %s\n", v); return 2; } ++i; }
     else if (!strcmp(a, "--out")) { if (!parse_size(v, &o.out_w, &o.out_h)) { fprintf(stderr, "bad --out %s\n", v); return 2; } ++i; }
@@ -542,7 +582,11 @@ int main(int argc, char** argv) {
     for (int i = 0; i < o.gpus; ++i) printf("%s%.3f", i ? ", " : "", (double)gathered[3 * i + 2] * 1e-6);
     printf("], \"per_rank_seconds\": [");
     for (int i = 0; i < o.gpus; ++i) printf("%s%.6f", i ? ", " : "", (double)gathered[3 * i + 2] * 1e-9);
-    printf("], \"cpu_binding\": [");  /* the CPUs each rank's thread was pinned to: those local to its GPU's PCIe root (null: not pinned) */
+    if (o.latency > 0 && !o.dry)
+      printf("], \"latency_us\": {\"frames\": %d, \"idle_gap_ms\": 1.0, \"median\": %.1f, \"p90\": %.1f, \"back_to_back_median\": %.1f, "
+             "\"what\": \"rank 0: host clock around fsr1_upscale_ex + hipStreamSynchronize of ONE step on one stream, from C\"}, \"cpu_binding\": [",
+             o.latency, ws[0].lat_med_us, ws[0].lat_p90_us, ws[0].lat_b2b_us);
+    else printf("], \"cpu_binding\": [");  /* the CPUs each rank's thread was pinned to: those local to its GPU's PCIe root (null: not pinned) */
     for (int i = 0; i < o.gpus; ++i) {
       if (ws[i].pinned_cpus) printf("%s\"%s\"", i ? ", " : "", ws[i].cpu_list); else printf("%snull", i ? ", " : "");
     }
