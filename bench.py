@@ -578,6 +578,7 @@ def main():
     ap.add_argument("--submit-only", action="store_true",
                     help="measure only the host's submission ceiling (steps/s through fsr1_pipeline_upscale on 16x16 frames) on every rank and print it; "
                          "with --gpus 8 --backend gloo --oversubscribe: eight processes contending on one host")
+    ap.add_argument("--no-submit-ceiling", action="store_true", help="skip the host submission ceiling block (profiling runs: its 16x16 launches would sit in the trace)")
     ap.add_argument("--no-telemetry-window", action="store_true",
                     help="skip the dedicated 1.2 s load window the per-rank clock / power figures are sampled in (the line then marks them unreliable)")
     ap.add_argument("--no-latency", action="store_true", help="skip the single-frame latency block (N = 1 only)")
@@ -1083,10 +1084,12 @@ def main():
 
     # the host's submission ceiling (outside every timed region): steps/s this rank's thread can push through the pipeline — every rank at
     # the same time, so that N ranks on one host contend as they do in the timed regions — against what the headline needs
-    if grouped:
-        dist.barrier()
-    submit = submission_ceiling(fsr, torch, device, args.streams)
-    submit_rows = gather_row([submit["steps_per_s"]], coll_device)
+    submit = submit_rows = None
+    if not args.no_submit_ceiling:
+        if grouped:
+            dist.barrier()
+        submit = submission_ceiling(fsr, torch, device, args.streams)
+        submit_rows = gather_row([submit["steps_per_s"]], coll_device)
 
     # per-rank shader clock and package power during the headline regions (sysfs, best effort) — one counters-only collective
     tele.close()
@@ -1190,10 +1193,10 @@ def main():
                                          extra={"one_stream": dict(zip(("mhz", "watts", "samples"), tele.summary("one_stream"))),
                                                 "latency": dict(zip(("mhz", "watts", "samples"), tele.summary("latency"))),
                                                 "violation_fields_rank0": sorted(viol1)[:24] if viol1 else None}),
-            "host_submission": dict(submit, per_rank_steps_per_s=[r[0] for r in submit_rows],
-                                    needed_steps_per_s=round(args.steps / total["seconds"], 0),
-                                    margin=round(min(r[0] for r in submit_rows) / (args.steps / total["seconds"]), 2),
-                                    note="margin = the slowest rank's ceiling / the steps per second the headline ran at: well above 1 means the host is not what a rank waits for"),
+            "host_submission": None if submit is None else dict(
+                submit, per_rank_steps_per_s=[r[0] for r in submit_rows], needed_steps_per_s=round(args.steps / total["seconds"], 0),
+                margin=round(min(r[0] for r in submit_rows) / (args.steps / total["seconds"]), 2),
+                note="margin = the slowest rank's ceiling / the steps per second the headline ran at: well above 1 means the host is not what a rank waits for"),
             "roofline": roof(dominant),
             "kernels": {k: roof(k) for k in kern},
             "pipeline_hbm": {"algorithmic_bytes_per_step": sum(alg[k] for k in kern),

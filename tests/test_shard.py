@@ -114,7 +114,13 @@ def test_bench_self_launch_two_ranks_on_the_visible_gpus():
     # round 5: per-rank clock / power travel in one more counters-only collective; at N > 1 only the headline regions run
     assert len(line["per_rank_mhz"]) == 2 and len(line["per_rank_watts"]) == 2
     assert line.get("also_measured") is None and "skipped at n_gpus > 1" in line["also_measured_note"]
-    assert "latency_us" not in line and "cpu_baseline" not in line and line["parity_class"] == "F-default"
+    assert "latency_us" not in line and "cpu_baseline" not in line and line["parity_class"] == "F-strict"  # (round 6: the default arithmetic of the bench)
+    # round 6: the telemetry comes from a dedicated window (>= 200 samples per rank), with the power cap, the partition mode, the CPUs each rank is
+    # pinned to and every rank's host submission ceiling
+    t = line["telemetry"]
+    assert len(t["samples_per_rank"]) == 2 and len(t["power_cap_w"]) == 2 and len(t["at_power_cap"]) == 2
+    assert t["reliable"] == (min(t["samples_per_rank"]) >= 200) and ("unreliable" in t) == (not t["reliable"])
+    assert "cpu_binding" in line["config"] and len(line["host_submission"]["per_rank_steps_per_s"]) == 2 and line["host_submission"]["margin"] > 0
 
 
 @pytest.mark.gpu
