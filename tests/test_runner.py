@@ -73,6 +73,23 @@ def test_runner_on_gpu(runner, pipeline):
 
 
 @pytest.mark.gpu
+def test_runner_strict_latency_and_cpu_binding(runner):
+    """Round 6: --math strict (FSR1_FLAG_MATH_STRICT) from the C host, --latency N (N single frames after 1 ms of idle GPU: host clock around
+    fsr1_upscale_ex + hipStreamSynchronize), and the per-GPU thread pinned to the CPUs local to its GPU (sysfs local_cpulist; --no-pin leaves it)."""
+    out = subprocess.run([runner, "--gpus", "1", "--frames", "1", "--in", "640x360", "--out", "1280x720", "--steps", "20", "--warmup", "3",
+                          "--math", "strict", "--pipeline", "auto", "--streams", "1", "--latency", "40"], capture_output=True, text=True, timeout=1200)
+    assert out.returncode == 0, out.stdout + out.stderr
+    d = json.loads(out.stdout.strip().splitlines()[-1])
+    assert d["math"] == "strict" and d["pipeline_run"] == "fused" and d["value"] > 1000.0
+    lat = d["latency_us"]
+    assert lat["frames"] == 40 and 5.0 < lat["back_to_back_median"] <= lat["p90"] * 1.5 and lat["median"] <= lat["p90"] < 5000.0
+    assert len(d["cpu_binding"]) == 1  # a CPU list where sysfs offers one, null otherwise
+    out = subprocess.run([runner, "--gpus", "1", "--frames", "1", "--in", "320x180", "--out", "640x360", "--steps", "5", "--warmup", "1", "--no-pin"],
+                         capture_output=True, text=True, timeout=1200)
+    assert out.returncode == 0 and json.loads(out.stdout.strip().splitlines()[-1])["cpu_binding"] == [None]
+
+
+@pytest.mark.gpu
 def test_runner_with_colour_stages(runner):
     """--stages: SRTM prologue + film grain + SRTM inverse fused into the single-launch pipeline, from the C host."""
     out = subprocess.run([runner, "--gpus", "1", "--frames", "2", "--in", "640x360", "--out", "1280x720", "--steps", "10",
