@@ -306,6 +306,7 @@ def bind_to_gpu_cpus(tele, enabled=True):
     link).  Best effort; returns what the line prints as config.cpu_binding."""
     info = {"numa_node": tele.numa_node, "local_cpus": tele.local_cpus, "applied": False}
     try:
+        info["_before"] = os.sched_getaffinity(0)  # (restored around the cpu_baseline leg, which is meant to use every host core; not printed)
         cpus = parse_cpulist(tele.local_cpus) & os.sched_getaffinity(0)
         if enabled and cpus:
             os.sched_setaffinity(0, cpus)
@@ -647,6 +648,7 @@ def main():
 
     tele = Telemetry(torch, dev_index)  # (the sampling thread runs from here on; figures are taken from labelled spans only)
     cpu_binding = bind_to_gpu_cpus(tele, enabled=not args.no_pin)
+    cpu_binding_before = cpu_binding.pop("_before", None) or os.sched_getaffinity(0)
     if args.submit_only:
         # the host's submission ceiling alone: every rank at the same time (a barrier in front), so that N ranks on one host contend as they
         # would in a run; one JSON line with every rank's rate
@@ -1219,7 +1221,13 @@ def main():
         check_stopwatch(line)  # sum of kernel times <= the step that contains them, or the line says "stopwatch_suspect"
         if world == 1 and not args.no_cpu_baseline and args.pipeline != "color" and not args.stages:
             kept = {}
-            line["cpu_baseline"] = cpu_baseline(fsr, in_w, in_h, out_w, out_h, keep=kept)
+            try:  # the reference on ALL host cores, as in every round: the rank's pinning to its GPU's NUMA node is lifted for this leg
+                if cpu_binding.get("applied"):
+                    os.sched_setaffinity(0, cpu_binding_before)
+                line["cpu_baseline"] = cpu_baseline(fsr, in_w, in_h, out_w, out_h, keep=kept)
+            finally:
+                if cpu_binding.get("applied"):
+                    os.sched_setaffinity(0, parse_cpulist(cpu_binding["local_cpus"]) & cpu_binding_before)
             if not args.no_parity and kept and args.storage == "rgba16f" and args.math in ("f", "strict", "exact") and args.pipeline in ("two-pass", "fused"):
                 # Image-level parity of THIS workload's arithmetic against the reference chain the cpu_baseline leg just evaluated
                 # (FsrEasuF -> RTNE binary16 -> FsrRcasF, ffx_fsr1.h:315-437, :684-769): the final image of the two dispatches, the fused

@@ -9,12 +9,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 print("| profile (`profiles/%s_*`) | Mpix/s | µs per step | EASU µs (frac of 8 TB/s) | RCAS µs (frac) | fused µs (frac) |" % tag)
 print("|---|---|---|---|---|---|")
-for f in sorted(glob.glob(os.path.join(ROOT, "profiles", tag + "_*.line"))):
+for f in sorted(glob.glob(os.path.join(ROOT, "profiles", tag + "_*.json"))):
     name = os.path.basename(f)[len(tag) + 1:-5]
-    if not os.path.exists(f[:-5] + ".json"):
-        continue  # (a trace without a PMC summary, e.g. the r04 *_two_streams kernel-trace of the pipelined regime)
-    line = json.loads(open(f).read())
-    prof = json.load(open(f[:-5] + ".json"))
+    prof = json.load(open(f))
+    line = prof.get("bench_line") if isinstance(prof, dict) else None  # (the bench line of the traced run travels inside the summary since round 6)
+    if not line or "kernels" not in prof:
+        continue  # (bench lines, parity reports: not profiles)
     h = line["config"].get("workload", "").find("math=h") >= 0
 
     def cell(kind, alg_key):
