@@ -988,6 +988,10 @@ def main():
             also["default_arithmetic_two_pass"] = also_entry(d_step, "the default (F) arithmetic, two dispatches: per stage <= 1 binary16 ULP, image level 99.99 % within 1 ULP / max 6 "
                                                                      "(the headline of rounds 1-5; `parity.default_arithmetic` has this run's histogram)", fn=pipe and piped(0, 0))
             also["default_arithmetic_fused"] = also_entry(df_step, "the default (F) arithmetic, EASU->RCAS in one launch", fn=pipe and piped(0, 1))
+            # ... and the default arithmetic's EASU as a kernel (the dominant kernel of rounds 1-5's headline), for continuity of the roofline figure
+            de_ms, de_info = kernel_ms(lambda i: fsr.easu(srcs[i % ring], mid, con=easu_con, flags=0))
+            also["default_arithmetic_two_pass"]["easu_kernel"] = {"avg_kernel_us": round(de_ms * 1e3, 2), "stopwatch": de_info, "algorithmic_bytes": in_bytes + out_bytes,
+                                                                  "hbm_frac": round((in_bytes + out_bytes) / (de_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}
         if args.storage == "rgba16f" and args.math in ("f", "strict"):
             # the reference's shipping default (FsrEasuH / FsrRcasH, FSR_Pass.hlsl:81-87) on the same frames, same K steps
             hflags = fsr.FLAG_MATH_PACKED_FP16
