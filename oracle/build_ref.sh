@@ -32,3 +32,12 @@ g++ $CXXFLAGS -I"$TMP" -I"$HERE" -c "$HERE/ref_wrap.cpp" -o "$TMP/ref_wrap.o"
 gcc -O2 -ffp-contract=off -fPIC -I"$REF" -c "$HERE/ref_con.c" -o "$TMP/ref_con.o"
 g++ -shared -fopenmp -o "$OUT/libfsr1_ref.so" "$TMP/ref_wrap.o" "$TMP/ref_con.o" -lm
 echo "build_ref: built $OUT/libfsr1_ref.so"
+# A SECOND compilation of the same sources with multiply-adds CONTRACTED (-ffp-contract=fast -mfma): what a shading-language compiler
+# is free to do to the reference's `a*b+c` expressions unless they are marked `precise`.  Never a parity target — it exists only so that
+# tests/ref_self_spread.py can publish how far two conformant compilations of the reference lie from each other (README.md), the
+# yardstick for the product's own distance from the pinned build.  Built only where the host CPU has FMA; constant setup stays uncontracted.
+if grep -qw fma /proc/cpuinfo; then
+  g++ ${CXXFLAGS/-ffp-contract=off/-ffp-contract=fast} -mfma -I"$TMP" -I"$HERE" -c "$HERE/ref_wrap.cpp" -o "$TMP/ref_wrap_fma.o"
+  g++ -shared -fopenmp -o "$OUT/libfsr1_ref_fma.so" "$TMP/ref_wrap_fma.o" "$TMP/ref_con.o" -lm
+  echo "build_ref: built $OUT/libfsr1_ref_fma.so (contracted twin, self-spread only)"
+fi

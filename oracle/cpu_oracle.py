@@ -184,6 +184,17 @@ def ref():
     return _Oracle(os.path.join(_HERE, "_ref", "libfsr1_ref.so"), "ref_", "ref_")
 
 
+def have_ref_fma():
+    return os.path.exists(os.path.join(_HERE, "_ref", "libfsr1_ref_fma.so"))
+
+
+def ref_fma():
+    """The reference compiled a second time with contracted multiply-adds (oracle/build_ref.sh): the self-spread yardstick
+    (tests/ref_self_spread.py), never a parity target."""
+    build()
+    return _Oracle(os.path.join(_HERE, "_ref", "libfsr1_ref_fma.so"), "ref_", "ref_")
+
+
 def half_ulp_diff(a, b):
     """|a-b| in units of binary16 ULPs after rounding both to binary16 (RTNE); NaN==NaN counts 0."""
     ha = np.asarray(a, np.float32).astype(np.float16).view(np.int16).astype(np.int32)
