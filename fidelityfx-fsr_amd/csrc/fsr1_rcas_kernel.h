@@ -31,7 +31,12 @@ template <> struct RcasPair<FSR1_FORMAT_R10G10B10A2_UNORM> { typedef uint32_t T 
 // XEDGE (with INTERIOR): the strip's own 128 columns and every row it reads are inside the image, but it is the image's first
 // and / or last wave-column: the apron column of lane 0 and / or lane 63 is outside, i.e. 0 (FSR_Pass.hlsl:45,61).  The interior
 // body with that one texel replaced, instead of the fully predicated one (2 of 30 wave-columns at 3840 pixels).
-template <int FMT, bool EXACT, bool OPTS, bool INTERIOR, bool COLOR, int FOUT, int RING, bool XEDGE = false>
+// UP (with INTERIOR): the strip is walked from its last row to its first.  Strips of odd strip-rows walk up, those of even ones down, so
+// that two vertically adjacent strips — resident on the same XCD at the same time (xcd_swizzle) — touch the two rows they share (each
+// one's apron is the other's edge row) at the same moment: both at their start or both at their end.  The second request then finds the
+// line in the XCD's L2 (or merges with the miss in flight) instead of fetching it again after 4 MB of other rows have passed through.
+// The taps keep their places (b above, h below): the sums' operand order, and so every bit of the result, is that of the downward walk.
+template <int FMT, bool EXACT, bool OPTS, bool INTERIOR, bool COLOR, int FOUT, int RING, bool XEDGE = false, bool UP = false>
 __device__ __forceinline__ void rcas_strip(const RcasArgs& a, int frame, int x0, int y0, int lane) {
   typedef typename Pixel<FMT>::T texel_t;
   typedef typename RcasPair<FMT>::T pair_t;
@@ -58,7 +63,8 @@ __device__ __forceinline__ void rcas_strip(const RcasArgs& a, int frame, int x0,
   auto zext = [](uint32_t o) { asm("" : "+v"(o)); return (size_t)o; };
 
   const int rows = a.rows;
-  auto row_y = [&](int k) { return y0 + k; };  // k-th row of the walk, k = -1 .. rows
+  static_assert(!UP || INTERIOR, "only strips that store every row walk up");
+  auto row_y = [&](int k) { return UP ? y0 + rows - 1 - k : y0 + k; };  // k-th row of the walk, k = -1 .. rows
   struct row_t { texel_t p0, p1, halo; };
   auto load = [&](int y, row_t& r) {
     if (!INTERIOR) r.halo = Pixel<FMT>::zero();
@@ -120,9 +126,9 @@ __device__ __forceinline__ void rcas_strip(const RcasArgs& a, int frame, int x0,
       // horizontal neighbours: pixel 0's left = the left lane's pixel 1, pixel 1's right = the right lane's pixel 0;
       // lanes 0 / 63 keep their apron texel
       const rgb_t d0 = neighbour<kDppWaveShr1>(hal, cur1), f1 = neighbour<kDppWaveShl1>(hal, cur0);
-      // b is the tap above, h the one below (ffx_fsr1.h:697-707)
-      rgb_t o0 = rcas_pixel<EXACT>(prev0, d0, cur0, cur1, next0, sharp, flags);
-      rgb_t o1 = rcas_pixel<EXACT>(prev1, cur0, cur1, f1, next1, sharp, flags);
+      // b is the tap above, h the one below (ffx_fsr1.h:697-707), whichever way the strip is walked
+      rgb_t o0 = rcas_pixel<EXACT>(UP ? next0 : prev0, d0, cur0, cur1, UP ? prev0 : next0, sharp, flags);
+      rgb_t o1 = rcas_pixel<EXACT>(UP ? next1 : prev1, cur0, cur1, f1, UP ? prev1 : next1, sharp, flags);
       if (INTERIOR || y < H) {
         const bool alpha = (flags & FSR1_FLAG_RCAS_PASSTHROUGH_ALPHA) != 0;  // :700-705 / FSR_Pass.hlsl:94
         if constexpr (COLOR) {
@@ -164,7 +170,10 @@ __global__ void __launch_bounds__(kRcasThreads) rcas_kernel(const RcasArgs a) {
   const bool interior_y = y0 >= 1 - a.rows_above && y0 + a.rows + 1 <= a.in.height + a.rows_below &&
                           y0 + a.rows <= a.in.height;  // (the interior body stores every row of the strip)
   const bool interior = interior_y && x0 >= 1 && x0 + kRcasWaveCols + 1 <= a.in.width;
-  if (interior) rcas_strip<FMT, EXACT, OPTS, true, COLOR, FOUT, RING>(a, frame, x0, y0, lane);
+  const bool up = (ty & 1) != 0;
+  if (interior && up) rcas_strip<FMT, EXACT, OPTS, true, COLOR, FOUT, RING, false, true>(a, frame, x0, y0, lane);
+  else if (interior) rcas_strip<FMT, EXACT, OPTS, true, COLOR, FOUT, RING>(a, frame, x0, y0, lane);
+  else if (interior_y && x0 + kRcasWaveCols <= a.in.width && up) rcas_strip<FMT, EXACT, OPTS, true, COLOR, FOUT, RING, true, true>(a, frame, x0, y0, lane);
   else if (interior_y && x0 + kRcasWaveCols <= a.in.width) rcas_strip<FMT, EXACT, OPTS, true, COLOR, FOUT, RING, true>(a, frame, x0, y0, lane);
   else rcas_strip<FMT, EXACT, OPTS, false, COLOR, FOUT, RING>(a, frame, x0, y0, lane);
 }
