@@ -84,7 +84,9 @@ def window_max(src32, ow, oh, con):
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=150.0)
+    ap.add_argument("--seed", type=int, default=20260930, help="content generator seed (the committed logs: the default; *_seed2: 7)")
     args = ap.parse_args()
+    g.manual_seed(args.seed)
     kinds = ["uniform", "smooth", "blocks", "edges", "gradient", "dark", "hdr", "text", "natural", "natural", "natural"]
     sizes = [(960, 540), (1280, 720), (1477, 831), (1001, 563), (640, 360)]
     ratios = [2.0, 2.0, 1.5, 1.3, 1.7, 1.0 + 1.0 / 3.0, 1.25, 1.9, 3.0]
