@@ -3,8 +3,11 @@
 // 8 B read + 8 B written per pixel (RGBA16F) against 80 VALU instructions: on MI355X the pass moves its bytes
 // at the chip's copy rate, so the kernel is built to touch every input byte as few
 // times as it can, to move 16 bytes per lane per memory instruction, and to spend no instruction on staging:
-//   * no LDS, no barrier: a wave owns a 128-column x 16-row strip and streams down it, a lane owning TWO
-//     adjacent columns (one 16-byte load and one 16-byte store per row);
+//   * no LDS, no barrier: a wave owns a 128-column x 16-row strip and streams along it, a lane owning TWO
+//     adjacent columns (one 16-byte load and one 16-byte store per row) — strips of even strip-rows from top to
+//     bottom, those of odd ones from bottom to top (round 6), so that vertically adjacent strips, resident on one
+//     XCD at the same time, reach the two rows they share at the same moment and the second request finds them in
+//     the L2: a 4K frame fetches 1.014 x its bytes instead of 1.25 x (fsr1_rcas_kernel.h, UP);
 //   * vertical neighbours (b above, h below) are the lane's own previous/next rows kept in registers;
 //     of the horizontal neighbours, two are the lane's own other pixel and two are the adjacent lanes'
 //     facing pixels, fetched in fp32 with DPP wave shifts (v_mov_b32_dpp wave_shr:1 / wave_shl:1);
@@ -27,8 +30,9 @@ constexpr int kRcasShallowRing = 2;  // rows in flight per lane when the launch 
 // Strip height.  Measured on MI355X at 3840x2160 (gpurun_out/): the pass runs at the same ~34 us for
 // 8..16-row strips and slows down beyond (24 rows 39 us, 32 rows 42-46 us, 64 rows 67 us) even when the
 // workgroups divide evenly over the CUs and however deep the per-lane prefetch ring is: what counts is the number
-// of independent row streams in flight, and the apron rows that shorter strips re-read are cheap next to it.
-// 16 rows (two apron rows per 16 = 12.5 % extra reads, mostly L2/MALL hits) unless that leaves fewer than four
+// of independent row streams in flight, and the apron rows that shorter strips re-read are cheap next to it
+// (and since the strips walk alternately up and down, round 6, hits in the L2: profiles/ab_r06/r6d2_pmc_rcas_updown.log).
+// 16 rows unless that leaves fewer than four
 // waves per SIMD, then 8 — unless the launch runs beside other frames' launches (FSR1_FLAG_FRAMES_OVERLAP, fsr1_pipeline): then the
 // neighbour's waves fill the chip and the bytes count again: 16 rows (round 4, two streams, us per frame: 1080p -> 4K 60.3-60.4 ->
 // 59.4-59.6, 1440p -> 4K 70.9 -> 69.7-70.0; on one stream the same strips LOSE 5 %: profiles/ab_r04/r4c5_two_stream_rcas_rows.log).
