@@ -132,6 +132,58 @@ def test_strict_on_hostile_content(fsr, kind, scale):
     assert int(bad.sum()) == 0, "%s %s fused strict vs easu(EXACT) -> rcas(default): %d values differ" % (kind, scale, int(bad.sum()))
 
 
+def _worst_tiles():
+    import json
+    import os
+    doc = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "strict_worst_tiles.json")))
+    return doc["threshold"], doc["tiles"]
+
+
+@pytest.mark.parametrize("k", range(8))
+def test_strict_on_the_adversarial_search_worst_tiles(fsr, k):
+    """The input tiles on which an evolution strategy found the default arithmetic furthest from the reference's operation order
+    (tools/experiments_r06/strict_adversarial.py, one per ratio; tests/golden/gen_strict_worst_tiles.py), tiled over an image of the
+    search's size at the ratio they were found at (every tile position, the recorded one among them: off 2x the sub-texel position is
+    rounded from the absolute coordinate): (a) easu(STRICT) stores EXACT's bits; (b) the distance the threshold is a bound of,
+    d = |default - EXACT| / (2^-24 M), M = the largest |R|,|G|,|B| of the pixel's 12 taps, stays below the threshold (48); (c) the
+    recorded distance is reproduced — the fixture still is the hard case it was when it was recorded."""
+    threshold, tiles = _worst_tiles()
+    t = tiles[k]
+    T, num, den = t["T"], t["num"], t["den"]
+    iw, ih = t["in"]
+    tile = torch.from_numpy(np.asarray(t["rgb_bits"], np.uint16).reshape(T, T, 3).view(np.int16).copy()).cuda().view(torch.float16)
+    src = torch.ones(ih, iw, 4, dtype=torch.float16, device="cuda")
+    src[..., :3] = tile.repeat(ih // T, iw // T, 1)
+    ow, oh = iw * num // den, ih * num // den
+    con = fsr.FsrEasuCon(iw, ih, iw, ih, ow, oh)
+    ex, st = (torch.zeros(oh, ow, 4, dtype=torch.float16, device="cuda") for _ in range(2))
+    fsr.easu(src, ex, con=con, flags=fsr.FLAG_MATH_EXACT)
+    fsr.easu(src, st, con=con, flags=fsr.FLAG_MATH_STRICT)
+    assert_same_bits(st, ex, "worst tile %d/%d EASU strict vs EXACT" % (num, den))
+    # the bound itself, on binary32 storage (no conversion between the two arithmetics' results and the comparison)
+    s32 = src.float().contiguous()
+    d32, e32 = (torch.zeros(oh, ow, 4, dtype=torch.float32, device="cuda") for _ in range(2))
+    fsr.easu(s32, d32, con=con)
+    fsr.easu(s32, e32, con=con, flags=fsr.FLAG_MATH_EXACT)
+    delta = (d32[..., :3].double() - e32[..., :3].double()).abs().amax(dim=-1)
+    c = np.asarray(con, np.uint32).view(np.float32)
+    fx = torch.floor(torch.arange(ow, device="cuda", dtype=torch.float32) * float(c[0]) + float(c[2])).long()  # ffx_fsr1.h:324-326
+    fy = torch.floor(torch.arange(oh, device="cuda", dtype=torch.float32) * float(c[1]) + float(c[3])).long()
+    mag = s32[..., :3].abs().amax(dim=-1)
+    M = torch.zeros(oh, ow, device="cuda")
+    for dy, dxs in ((-1, (0, 1)), (0, (-1, 0, 1, 2)), (1, (-1, 0, 1, 2)), (2, (0, 1))):  # the 12 taps b c / e f g h / i j k l / n o
+        rows = mag[(fy + dy).clamp(0, ih - 1)]
+        for dx in dxs:
+            M = torch.maximum(M, rows[:, (fx + dx).clamp(0, iw - 1)])
+    d = delta / (M.double().clamp_min(2.0 ** -126) * 2.0 ** -24)
+    assert float(d.max()) < threshold, "d = %.2f reaches the F-strict threshold %d" % (float(d.max()), threshold)
+    # the recorded position: pixels whose 'f' texel lies in tile `at_tile`
+    tx, ty = t["at_tile"]
+    own = ((fy // T == ty)[:, None] & (fx // T == tx)[None, :])
+    here = float(d[own].max())
+    assert here > 0.95 * t["max_d_measured"], "the fixture lost its worst case: d = %.2f at the recorded tile, recorded %.2f" % (here, t["max_d_measured"])
+
+
 @pytest.mark.parametrize("name", ["540p_to_1080p", "1080p_to_4k", "1440p_to_4k", "831p_to_1080p", "ragged_2x", "ragged_1p7x", "tiny_2x", "minify"])
 @pytest.mark.parametrize("fmt", ["f16", "u8"])
 def test_every_strict_pipeline_is_easu_exact_then_rcas_default(fsr, name, fmt):
