@@ -139,13 +139,13 @@ def _worst_tiles():
     return doc["threshold"], doc["tiles"]
 
 
-@pytest.mark.parametrize("k", range(8))
+@pytest.mark.parametrize("k", range(10))
 def test_strict_on_the_adversarial_search_worst_tiles(fsr, k):
     """The input tiles on which an evolution strategy found the default arithmetic furthest from the reference's operation order
-    (tools/experiments_r06/strict_adversarial.py, one per ratio; tests/golden/gen_strict_worst_tiles.py), tiled over an image of the
+    (tools/experiments_r06/strict_adversarial.py: one per ratio of the first search, the two beyond d = 35 of the second; tests/golden/gen_strict_worst_tiles.py), tiled over an image of the
     search's size at the ratio they were found at (every tile position, the recorded one among them: off 2x the sub-texel position is
     rounded from the absolute coordinate): (a) easu(STRICT) stores EXACT's bits; (b) the distance the threshold is a bound of,
-    d = |default - EXACT| / (2^-24 M), M = the largest |R|,|G|,|B| of the pixel's 12 taps, stays below the threshold (48); (c) the
+    d = |default - EXACT| / (2^-24 M), M = the largest |R|,|G|,|B| of the pixel's 12 taps, stays below the threshold (56); (c) the
     recorded distance is reproduced — the fixture still is the hard case it was when it was recorded."""
     threshold, tiles = _worst_tiles()
     t = tiles[k]

@@ -1,7 +1,7 @@
 """Round 6: how many pixels per TILE fail F-strict's rounding-boundary test — the re-evaluation costs one pass of ~520 wave-instructions per
 started group of 64 queued pixels of a tile, so the distribution per tile, not the fraction per image, is what its time follows.
 The test is re-stated in torch on the default arithmetic's binary32 output (RGBA32F out: the value before the store conversion):
-e = 48 * 2^-24 * M capped per channel by the dering interval's width, flagged when binary16(x - e) != binary16(x + e) in some channel.
+e = K * 2^-24 * M (K = 48 until the adversarial search, 56 since) capped per channel by the dering interval's width, flagged when binary16(x - e) != binary16(x + e) in some channel.
 Writes gpurun_out/r06_strict_flag_census.json."""
 import importlib
 import json
@@ -62,9 +62,10 @@ if __name__ == "__main__":
     synth1440 = torch.from_numpy(fsr.frames.synthetic_frame(2560, 1440, k=1)).to(dev)
     nat = torch.from_numpy(image_parity.natural_frame().astype(np.float32)).to(dev)
     nat = torch.cat([nat[..., :3], torch.ones_like(nat[..., :1])], dim=-1).half().contiguous() if nat.shape[-1] >= 3 else nat
-    for K in (32, 48, 64):
+    for K in (32, 48, 56, 64):
         doc["bench frame 1080p->4K, 64x16 tiles, K=%d" % K] = census(synth, 3840, 2160, K, 64, 16, 1)
     doc["bench frame 1080p->4K, 64x32 tiles, K=48"] = census(synth, 3840, 2160, 48, 64, 32, 1)
+    doc["bench frame 1080p->4K, 64x32 tiles, K=56"] = census(synth, 3840, 2160, 56, 64, 32, 1)
     doc["bench frame 1440p->4K, 64x32 tiles, K=48"] = census(synth1440, 3840, 2160, 48, 64, 32, 0)
     nh, nw = nat.shape[:2]
     doc["natural %dx%d 2x, 64x16 tiles, K=48" % (nw, nh)] = census(nat, 2 * nw, 2 * nh, 48, 64, 16, 1)
