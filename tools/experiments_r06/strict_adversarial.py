@@ -46,7 +46,7 @@ def image_of(tiles, ny, nx):
 def random_tiles(n, T, g):
     """Fresh tiles of several kinds (binary16 bit patterns as int16, non-negative finite values)."""
     r = lambda *s: torch.rand(*s, device=dev, generator=g)
-    kind = torch.randint(0, 6, (n, 1, 1, 1), device=dev, generator=g)
+    kind = torch.randint(0, 7, (n, 1, 1, 1), device=dev, generator=g)
     u = r(n, T, T, 3)
     v = torch.where(kind == 0, u, torch.zeros_like(u))
     v = torch.where(kind == 1, u ** 6, v)                                                  # dark
@@ -56,6 +56,8 @@ def random_tiles(n, T, g):
     grad = (ramp[None, :, None, None] * r(n, 1, 1, 3) + ramp[None, None, :, None] * r(n, 1, 1, 3)) * 0.5 + 0.05 * u
     v = torch.where(kind == 4, grad, v)
     v = torch.where(kind == 5, (r(n, T, T, 1) > 0.8).float() * r(n, 1, 1, 3), v)            # sparse bright texels
+    # on / off patterns of HDR range (what the second search's worst tiles look like): each channel of each texel either `lo` or `hi`
+    v = torch.where(kind == 6, torch.where(u > r(n, 1, 1, 1), 100.0 + 400.0 * r(n, 1, 1, 3), 0.01 + 0.05 * r(n, 1, 1, 3)), v)
     return v.clamp(0, 60000.0).half()
 
 
@@ -63,7 +65,7 @@ def mutate(parents, g, T):
     """One mutation per child, chosen at random; operates on binary16 values (bit patterns for the ULP nudges)."""
     n = parents.shape[0]
     c = parents.clone()
-    op = torch.randint(0, 8, (n,), device=dev, generator=g)
+    op = torch.randint(0, 9, (n,), device=dev, generator=g)
     bits = c.view(torch.int16)
     # 0, 1: nudge k random texel channels by a few binary16 ULPs
     k_mask = torch.rand(n, T, T, 3, device=dev, generator=g) < (torch.rand(n, 1, 1, 1, device=dev, generator=g) * 0.15 + 0.01)
@@ -96,6 +98,12 @@ def mutate(parents, g, T):
     bits = c.view(torch.int16)
     pm = (torch.randint(0, 2, (n, T, T, 3), device=dev, generator=g, dtype=torch.int32) * 2 - 1)
     bits.copy_(torch.where(((op == 7)[:, None, None, None]) & one, (bits.to(torch.int32) + pm).clamp(0, 0x7BFF).to(torch.int16), bits))
+    # 8: flip a few texel channels between the tile's smallest and largest value (on / off patterns: the sign pattern of the weight errors)
+    cf = c.float()
+    lo, hi = cf.amin(dim=(1, 2, 3), keepdim=True), cf.amax(dim=(1, 2, 3), keepdim=True)
+    f_mask = torch.rand(n, T, T, 3, device=dev, generator=g) < 0.03
+    flipped = torch.where(cf > 0.5 * (lo + hi), lo, hi).half()
+    c.copy_(torch.where(((op == 8)[:, None, None, None]) & f_mask, flipped, c))
     return c
 
 
