@@ -93,3 +93,24 @@ def test_no_experiment_switches_in_the_product_sources():
             if "getenv(" in line and "FSR1_ROCTX" not in line:
                 hits.append("%s:%d: %s" % (os.path.relpath(f, ROOT), n, line.strip()))
     assert not hits, hits
+
+
+def test_strict_threshold_and_its_fixture_agree():
+    """tests/golden/strict_worst_tiles.json (the adversarial searches' worst input tiles, tests/test_gpu_strict.py) names the threshold its
+    distances are judged against: it must be the kernels' kEasuStrictK, and every recorded distance must lie below it with the margin the
+    header states (the threshold is 1.5 x the largest distance any search has produced)."""
+    import json
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "include", "fsr1_device_easu.hpp")).read()
+    k = float(re.search(r"constexpr float kEasuStrictK = ([0-9.]+)f;", src).group(1))
+    doc = json.load(open(os.path.join(root, "tests", "golden", "strict_worst_tiles.json")))
+    assert doc["threshold"] == k
+    assert len(doc["tiles"]) >= 10
+    worst = max(t["max_d_measured"] for t in doc["tiles"])
+    assert worst * 1.5 <= k + 0.5, "kEasuStrictK = %g is less than 1.5 x the largest recorded distance %.1f" % (k, worst)
+    for t in doc["tiles"]:
+        T = t["T"]
+        assert len(t["rgb_bits"]) == T and all(len(r) == T and all(len(p) == 3 for p in r) for r in t["rgb_bits"])
+        assert (t["in"][0] * t["num"]) % t["den"] == 0 and (t["in"][1] * t["num"]) % t["den"] == 0
